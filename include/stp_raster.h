@@ -1,0 +1,140 @@
+/*
+ * stp_raster.h -- C ABI of libstp_raster.so, the MI355X (gfx950) sorted Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the hot path of r4dl/StopThePop-Rasterization.  Each entry point
+ * replaces one member of the reference's C++ API `CudaRasterizer::Rasterizer`
+ * (reference cuda_rasterizer/rasterizer.h:184-258), which is what the reference's pybind layer
+ * (rasterize_points.cu:43-253, ext.cpp:15-19) calls.  Signatures are plain C: device pointers, sizes,
+ * a POD settings struct, allocator callbacks and a stream handle -- no torch, no C++ types.
+ *
+ * Conventions (identical to the reference unless stated):
+ *   - all array arguments are DEVICE pointers to contiguous fp32/int32 data; an absent optional
+ *     input (shs / colors_precomp / scales / rotations / cov3D_precomp) is NULL
+ *     (reference tests pointers against nullptr: forward.cu:126,200; rasterizer_impl.cu:367,473,500);
+ *   - matrices are 16 floats in the 3DGS row-vector layout (p_hom = [x y z 1] @ M), i.e. element
+ *     m[4*col+row] in kernel indexing (auxiliary.h:103-149);
+ *   - `stream` is a hipStream_t (NULL = the null stream).  The reference launches on the legacy
+ *     default stream; we launch everything on the stream the caller passes;
+ *   - functions return >= 0 on success and a negative StpStatus on failure; stp_last_error()
+ *     returns a thread-local message for the most recent failure.
+ */
+#ifndef STP_RASTER_H_INCLUDED
+#define STP_RASTER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STP_ABI_VERSION 1
+
+/* Replaces CudaRasterizer::SplattingSettings + SortSettings + SortQueueSizes + CullingSettings
+   (rasterizer.h:27-135) and their json parser (rasterizer.h:160-182): the host binding fills this
+   from the Python settings dict. */
+typedef struct StpSettings {
+    int32_t sort_mode;                /* 0 GLOBAL, 1 PER_PIXEL_FULL, 2 PER_PIXEL_KBUFFER, 3 HIERARCHICAL (rasterizer.h:27-33) */
+    int32_t sort_order;               /* 0 VIEWSPACE_Z, 1 DISTANCE, 2 PER_TILE_DEPTH_CENTER, 3 PER_TILE_DEPTH_MAXPOS (:35-41) */
+    int32_t queue_tile_4x4;           /* parsed, unused (the reference hard-wires 64: hierarchical_render.cuh:286-287) */
+    int32_t queue_tile_2x2;           /* hierarchical MID queue: 8, 12 or 20 (rasterizer.h:56) */
+    int32_t queue_per_pixel;          /* hierarchical HEAD queue (4, 8, 16; backward also 12) or k-buffer window */
+    int32_t rect_bounding;            /* rasterizer.h:79-85 */
+    int32_t tight_opacity_bounding;
+    int32_t tile_based_culling;
+    int32_t hierarchical_4x4_culling;
+    int32_t load_balancing;           /* performance hint only; results do not depend on it */
+    int32_t proper_ewa_scaling;
+    /* Extension (not in the reference): restrict binning + rendering to tile rows [tile_y0, tile_y1)
+       for tile-row sharding of one frame over several GPUs.  tile_y1 <= 0 selects all rows. */
+    int32_t tile_y0;
+    int32_t tile_y1;
+} StpSettings;
+
+typedef enum StpStatus {
+    STP_OK = 0,
+    STP_ERR_INVALID_ARGUMENT = -1,
+    STP_ERR_NEEDS_SCALE_ROTATION = -2,  /* sorted modes build Sigma^-1 from scales+rotations (forward.cu:208-220) */
+    STP_ERR_QUEUE_SIZE = -3,            /* "Not supported head/mid queue size" (forward.cu:455-480, backward.cu:751-760) */
+    STP_ERR_SORT_MODE = -4,
+    STP_ERR_NO_BACKWARD = -5,           /* "Backward not supported for full per-pixel sort" (backward.cu:733-736) */
+    STP_ERR_HIP = -6,                   /* a HIP runtime call or kernel failed; message has the detail */
+    STP_ERR_ALLOC = -7,                 /* an allocator callback returned NULL */
+    STP_ERR_PREFILTERED = -8            /* a point was culled although prefiltered was set (auxiliary.h:228-232) */
+} StpStatus;
+
+/* Replaces the three `std::function<char*(size_t)>` buffer-resize callbacks of Rasterizer::forward
+   (rasterizer.h:196-198; rasterize_points.cu:33-41).  Must return a device pointer to at least
+   `bytes` bytes, valid until the matching backward has run. */
+typedef void* (*stp_alloc_fn)(void* user, size_t bytes);
+
+/* Replaces CudaRasterizer::Rasterizer::forward (rasterizer.h:195-220, rasterizer_impl.cu:221-413).
+   Returns num_rendered (the number of (tile, Gaussian) duplicates) or a negative StpStatus.
+   Contains exactly one host synchronisation (the read-back of num_rendered, as in
+   rasterizer_impl.cu:317).  `radii` may be NULL (an internal array is used, rasterizer_impl.cu:259-262).
+   `out_color` is (3,H,W), written for every pixel of the selected tile rows. */
+int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user,
+                stp_alloc_fn binning_alloc, void* binning_user,
+                stp_alloc_fn image_alloc, void* image_user,
+                int P, int D, int M,
+                const float* background, int width, int height,
+                const StpSettings* settings,
+                const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier,
+                const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* inv_viewprojmatrix,
+                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
+                float* out_color, int* radii, int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:222-257, rasterizer_impl.cu:417-526).
+   geom/binning/image buffers are the ones the forward allocated; R is the forward's return value.
+   All dL_d* outputs must be zero-filled by the caller (rasterize_points.cu:178-186). */
+int stp_backward(int P, int D, int M, int R,
+                 const float* background, int width, int height,
+                 const StpSettings* settings,
+                 const float* means3D, const float* shs, const float* opacities, const float* colors_precomp,
+                 const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                 const float* viewmatrix, const float* projmatrix, const float* inv_viewprojmatrix,
+                 const float* cam_pos, float tan_fovx, float tan_fovy,
+                 const float* pixel_colors, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer,
+                 const float* dL_dpix,
+                 float* dL_dmean2D /* P x 3 */, float* dL_dconic /* P x 4 */, float* dL_dopacity /* P */,
+                 float* dL_dcolor /* P x 3 */, float* dL_dmean3D /* P x 3 */, float* dL_dcov3D /* P x 6 */,
+                 float* dL_dsh /* P x M x 3 */, float* dL_dscale /* P x 3 */, float* dL_drot /* P x 4 */,
+                 int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:188-193, rasterizer_impl.cu:161-173).
+   `present` is P bytes (bool). */
+int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Sizes of the three scratch buffers (the reference's `required<State>()`, rasterizer_impl.h:68-75). */
+size_t stp_geometry_buffer_size(int P, const StpSettings* settings);
+size_t stp_binning_buffer_size(int R);
+size_t stp_image_buffer_size(int width, int height);
+
+/* Introspection of the (otherwise opaque) scratch buffers, for parity tests and debugging.
+   Fills byte offset and element count of a named sub-array; returns 0 or STP_ERR_INVALID_ARGUMENT.
+   geometry names: depths clamped radii rects2D means2D cov3D cov3D_inv conic_opacity rgb tiles_touched point_offsets
+   binning names : point_list point_list_unsorted keys keys_unsorted
+   image names   : final_T n_contrib ranges */
+int stp_geometry_layout(int P, const StpSettings* settings, const char* name, size_t* offset, size_t* count);
+int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count);
+int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count);
+
+/* Stage timer, the counterpart of the reference's `Timer` (rasterizer_impl.h:77-147; stages
+   "Preprocess","Duplicate","Sort","Render", rasterizer_impl.cu:248) plus "BwdRender","BwdPreprocess".
+   When enabled, every forward/backward records hipEvents around its stages on the call's stream;
+   stp_timing_read synchronises those events and returns the last call's milliseconds
+   (6 floats, unmeasured stages are -1). */
+void stp_timing_enable(int enabled);
+int stp_timing_read(float* ms6);
+
+const char* stp_last_error(void);
+int stp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

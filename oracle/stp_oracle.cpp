@@ -202,13 +202,16 @@ inline M3 compute_cov2D_full(V3 t, float fx, float fy, float tan_fovx, float tan
 }
 
 // ref: stopthepop_common.cuh:44-55.  pack = 3 x float4: [S00 S01 S02 .][S11 S12 S22 .][u0 u1 u2 .]
+// Canonical evaluation order (shared with the HIP kernels so that depth keys compare bit-for-bit):
+// every dot product is fma(c, z, fma(b, y, a*x)) with correctly rounded fused multiply-adds, the
+// reciprocal is the IEEE quotient 1/x.  (The CUDA reference lets nvcc contract these sums as it likes.)
 inline float depth_along_ray(const float* pk, V3 v)
 {
-    const float a0 = pk[0] * v.x + pk[1] * v.y + pk[2] * v.z;
-    const float a1 = pk[1] * v.x + pk[4] * v.y + pk[5] * v.z;
-    const float a2 = pk[2] * v.x + pk[5] * v.y + pk[6] * v.z;
-    const float num = pk[8] * v.x + pk[9] * v.y + pk[10] * v.z;
-    const float den = a0 * v.x + a1 * v.y + a2 * v.z;
+    const float a0 = fmaf(pk[2], v.z, fmaf(pk[1], v.y, pk[0] * v.x));
+    const float a1 = fmaf(pk[5], v.z, fmaf(pk[4], v.y, pk[1] * v.x));
+    const float a2 = fmaf(pk[6], v.z, fmaf(pk[5], v.y, pk[2] * v.x));
+    const float num = fmaf(pk[10], v.z, fmaf(pk[9], v.y, pk[8] * v.x));
+    const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
     const float rcp_den = frcp(std::max(0.00001f, den));
     return num * rcp_den;
 }
@@ -1073,7 +1076,7 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                 const V3 dir = view_ray(c.inv_vp, c.cam, {(float)px, (float)py}, W, H);
                 float T = 1.0f, C[3] = {0, 0, 0};
                 bool done = false;
-                uint32_t contributor = 0;
+                uint32_t contributor = 0, last_contributor = 0;
                 win.clear();
                 uint32_t next = r0;
                 auto refill = [&](uint32_t count) {
@@ -1086,16 +1089,20 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                     merge_old_new(win, nw.data(), (int)nw.size());
                 };
                 auto blend = [&](size_t count) {
-                    size_t i = 0;
-                    for (; i < count && i < win.size() && !done; i++) {
+                    for (size_t i = 0; i < count && i < win.size() && !done; i++) {
                         contributor++;
                         const int id = win[i].id;
-                        float G, alpha;
-                        if (!eval_alpha(f, id, px, py, G, alpha)) continue;
+                        const float* co = &f.conic_opacity[4 * (size_t)id];
+                        const float dx = f.means2D[2 * (size_t)id] - (float)px, dy = f.means2D[2 * (size_t)id + 1] - (float)py;
+                        const float power = opacity_factor(dx, dy, co); // positive form (ref: resorted_render.cuh:621-630)
+                        if (power < 0.0f) continue;
+                        const float alpha = std::min(0.99f, co[3] * expf(-power));
+                        if (alpha < ALPHA_THRESHOLD) continue;
                         const float test_T = T * (1 - alpha);
                         if (test_T < T_THRESHOLD) { done = true; break; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)id + ch] * alpha * T;
                         T = test_T;
+                        last_contributor = contributor;
                     }
                     win.erase(win.begin(), win.begin() + std::min(count, win.size()));
                 };
@@ -1104,7 +1111,7 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                 if (!done) blend(win.size());
                 const size_t pid = (size_t)W * py + px;
                 f.final_T[pid] = T;
-                f.n_contrib[pid] = contributor;
+                f.n_contrib[pid] = last_contributor;
                 for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
             }
     }

@@ -1,0 +1,377 @@
+// stp_api.hip -- the C ABI of libstp_raster.so (declared in include/stp_raster.h) and the host
+// orchestration of one frame.  Replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (reference cuda_rasterizer/rasterizer_impl.cu:221-413, 417-526, 161-173) and the state carving of
+// rasterizer_impl.cu:175-217.
+//
+// Stage order of a forward is the reference's: preprocess -> inclusive scan -> (one host read-back of
+// num_rendered) -> duplicate -> radix sort on bits [0,32+bit) -> tile ranges -> render.  Everything is
+// enqueued on the caller's stream; the only host synchronisation is the read-back.
+#include "stp_internal.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+namespace stp {
+
+static thread_local std::string g_last_error;
+static bool g_timing = false;
+
+struct StageTimer { // counterpart of the reference's Timer (rasterizer_impl.h:77-147)
+    hipEvent_t ev[8] = {};
+    bool have[8] = {};
+    bool created = false;
+    void ensure()
+    {
+        if (created) return;
+        for (auto& e : ev) (void)hipEventCreate(&e);
+        created = true;
+    }
+    void mark(int i, hipStream_t st)
+    {
+        if (!g_timing) return;
+        ensure();
+        (void)hipEventRecord(ev[i], st);
+        have[i] = true;
+    }
+    void reset_fwd() { for (int i = 0; i < 5; i++) have[i] = false; }
+    void reset_bwd() { for (int i = 5; i < 8; i++) have[i] = false; }
+};
+static StageTimer g_timer; // events 0..4: forward stage boundaries, 5..7: backward stage boundaries
+
+static int fail(int code, const std::string& msg)
+{
+    g_last_error = msg;
+    return code;
+}
+static int fail_hip(hipError_t e, const char* what)
+{
+    return fail(STP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total, NamedOffset* names, int* n_names)
+{
+    Carver c(base);
+    GeometryState g{};
+    size_t off;
+    int n = 0;
+    auto note = [&](const char* nm, size_t o, size_t cnt) { if (names) names[n] = {nm, o, cnt}; n++; };
+    g.status = c.take<uint32_t>(64, &off);
+    g.depths = c.take<float>(P, &off); note("depths", off, P);
+    g.clamped = c.take<uint8_t>(3 * P, &off); note("clamped", off, 3 * P);
+    g.internal_radii = c.take<int32_t>(P, &off); note("radii", off, P);
+    g.rects2D = c.take<float2>(P, &off); note("rects2D", off, 2 * P);
+    g.means2D = c.take<float2>(P, &off); note("means2D", off, 2 * P);
+    g.cov3D = c.take<float>(6 * P, &off); note("cov3D", off, 6 * P);
+    if (with_inv) { g.cov3D_inv = c.take<float4>(3 * P, &off); note("cov3D_inv", off, 12 * P); }
+    g.conic_opacity = c.take<float4>(P, &off); note("conic_opacity", off, 4 * P);
+    g.rgb = c.take<float>(3 * P, &off); note("rgb", off, 3 * P);
+    g.tiles_touched = c.take<uint32_t>(P, &off); note("tiles_touched", off, P);
+    g.point_offsets = c.take<uint32_t>(P, &off); note("point_offsets", off, P);
+    g.scan_temp_bytes = scan_temp_bytes(P);
+    g.scan_temp = c.take<char>(g.scan_temp_bytes);
+    if (total) *total = c.total();
+    if (n_names) *n_names = n;
+    return g;
+}
+
+ImageState carve_image(char* base, size_t N, size_t T, size_t* total, NamedOffset* names, int* n_names)
+{
+    Carver c(base);
+    ImageState s{};
+    size_t off;
+    int n = 0;
+    auto note = [&](const char* nm, size_t o, size_t cnt) { if (names) names[n] = {nm, o, cnt}; n++; };
+    s.final_T = c.take<float>(N, &off); note("final_T", off, N);
+    s.n_contrib = c.take<uint32_t>(N, &off); note("n_contrib", off, N);
+    s.ranges = c.take<uint2>(T, &off); note("ranges", off, 2 * T);
+    if (total) *total = c.total();
+    if (n_names) *n_names = n;
+    return s;
+}
+
+BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* names, int* n_names)
+{
+    Carver c(base);
+    BinningState b{};
+    size_t off;
+    int n = 0;
+    auto note = [&](const char* nm, size_t o, size_t cnt) { if (names) names[n] = {nm, o, cnt}; n++; };
+    b.point_list = c.take<uint32_t>(R, &off); note("point_list", off, R);
+    b.point_list_unsorted = c.take<uint32_t>(R, &off); note("point_list_unsorted", off, R);
+    b.keys = c.take<uint64_t>(R, &off); note("keys", off, R);
+    b.keys_unsorted = c.take<uint64_t>(R, &off); note("keys_unsorted", off, R);
+    b.sort_temp_bytes = sort_temp_bytes(R);
+    b.sort_temp = c.take<char>(b.sort_temp_bytes);
+    if (total) *total = c.total();
+    if (n_names) *n_names = n;
+    return b;
+}
+
+static int check_settings(const StpSettings& s, bool backward)
+{
+    if (s.sort_mode < MODE_GLOBAL || s.sort_mode > MODE_HIER) return fail(STP_ERR_SORT_MODE, "invalid sort mode");
+    if (s.sort_order < ORDER_Z || s.sort_order > ORDER_PTD_MAX) return fail(STP_ERR_SORT_MODE, "invalid sort order");
+    if (backward && s.sort_mode == MODE_FULL) return fail(STP_ERR_NO_BACKWARD, "Backward not supported for full per-pixel sort");
+    if (s.sort_mode == MODE_HIER) {
+        const int h = s.queue_per_pixel, m = s.queue_tile_2x2;
+        if (!(m == 8 || m == 12 || m == 20)) return fail(STP_ERR_QUEUE_SIZE, "Not supported mid queue size");
+        const bool head_ok = backward ? (h == 4 || h == 8 || h == 12 || h == 16) : (h == 4 || h == 8 || h == 16);
+        if (!head_ok) return fail(STP_ERR_QUEUE_SIZE, "Not supported head queue size");
+    }
+    return 0;
+}
+
+static void fill_frame(FrameParams& f, int P, int D, int M, const float* background, int width, int height, const StpSettings& s,
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                       const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                       const float* viewmatrix, const float* projmatrix, const float* inv_viewprojmatrix, const float* cam_pos,
+                       float tan_fovx, float tan_fovy, int prefiltered)
+{
+    f.P = P; f.D = D; f.M = M; f.W = width; f.H = height;
+    f.gx = (width + TILE - 1) / TILE; f.gy = (height + TILE - 1) / TILE;
+    f.ty0 = 0; f.ty1 = f.gy;
+    if (s.tile_y1 > 0) {
+        f.ty0 = s.tile_y0 < 0 ? 0 : (s.tile_y0 > f.gy ? f.gy : s.tile_y0);
+        f.ty1 = s.tile_y1 > f.gy ? f.gy : s.tile_y1;
+        if (f.ty1 < f.ty0) f.ty1 = f.ty0;
+    }
+    f.focal_y = (float)height / (2.0f * tan_fovy); // reference rasterizer_impl.cu:251-252
+    f.focal_x = (float)width / (2.0f * tan_fovx);
+    f.tan_fovx = tan_fovx; f.tan_fovy = tan_fovy; f.scale_modifier = scale_modifier; f.s = s;
+    f.background = background; f.means3D = means3D; f.shs = shs; f.colors_precomp = colors_precomp; f.opacities = opacities;
+    f.scales = scales; f.rotations = rotations; f.cov3D_precomp = cov3D_precomp; f.viewmatrix = viewmatrix; f.projmatrix = projmatrix;
+    f.inv_viewprojmatrix = inv_viewprojmatrix; f.cam_pos = cam_pos; f.prefiltered = prefiltered;
+}
+
+} // namespace stp
+
+using namespace stp;
+
+#define STP_TRY(expr, what)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return fail_hip(_e, what);      \
+    } while (0)
+#define STP_DEBUG_SYNC(what)                                                     \
+    do {                                                                         \
+        if (debug) {                                                             \
+            hipError_t _e = hipStreamSynchronize(st);                            \
+            if (_e != hipSuccess) return fail_hip(_e, what);                     \
+        }                                                                        \
+    } while (0)
+
+extern "C" {
+
+int stp_abi_version(void) { return STP_ABI_VERSION; }
+const char* stp_last_error(void) { return g_last_error.c_str(); }
+
+size_t stp_geometry_buffer_size(int P, const StpSettings* settings)
+{
+    size_t total = 0;
+    carve_geometry(nullptr, (size_t)P, settings ? requires_depth_along_ray(*settings) : true, &total);
+    return total;
+}
+size_t stp_binning_buffer_size(int R)
+{
+    size_t total = 0;
+    carve_binning(nullptr, (size_t)(R > 0 ? R : 0), &total);
+    return total;
+}
+size_t stp_image_buffer_size(int width, int height)
+{
+    size_t total = 0;
+    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    carve_image(nullptr, (size_t)width * height, T, &total);
+    return total;
+}
+
+static int find_name(const NamedOffset* names, int n, const char* name, size_t* offset, size_t* count)
+{
+    for (int i = 0; i < n; i++)
+        if (std::strcmp(names[i].name, name) == 0) {
+            if (offset) *offset = names[i].offset;
+            if (count) *count = names[i].count;
+            return 0;
+        }
+    return fail(STP_ERR_INVALID_ARGUMENT, std::string("unknown sub-array name: ") + name);
+}
+int stp_geometry_layout(int P, const StpSettings* settings, const char* name, size_t* offset, size_t* count)
+{
+    NamedOffset names[16]; int n = 0;
+    carve_geometry(nullptr, (size_t)P, settings ? requires_depth_along_ray(*settings) : true, nullptr, names, &n);
+    return find_name(names, n, name, offset, count);
+}
+int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count)
+{
+    NamedOffset names[8]; int n = 0;
+    carve_binning(nullptr, (size_t)(R > 0 ? R : 0), nullptr, names, &n);
+    return find_name(names, n, name, offset, count);
+}
+int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count)
+{
+    NamedOffset names[8]; int n = 0;
+    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    carve_image(nullptr, (size_t)width * height, T, nullptr, names, &n);
+    return find_name(names, n, name, offset, count);
+}
+
+void stp_timing_enable(int enabled) { g_timing = enabled != 0; }
+
+int stp_timing_read(float* ms6)
+{
+    if (!ms6) return fail(STP_ERR_INVALID_ARGUMENT, "null output");
+    for (int i = 0; i < 6; i++) ms6[i] = -1.0f;
+    if (!g_timer.created) return 0;
+    auto span = [&](int from, int to, float* out) {
+        if (!(g_timer.have[from] && g_timer.have[to])) return;
+        if (hipEventSynchronize(g_timer.ev[to]) != hipSuccess) return;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, g_timer.ev[from], g_timer.ev[to]) == hipSuccess) *out = ms;
+    };
+    span(0, 1, &ms6[0]); // Preprocess (+ scan + read-back)
+    span(1, 2, &ms6[1]); // Duplicate
+    span(2, 3, &ms6[2]); // Sort (+ ranges)
+    span(3, 4, &ms6[3]); // Render
+    span(5, 6, &ms6[4]); // BwdRender
+    span(6, 7, &ms6[5]); // BwdPreprocess
+    return 0;
+}
+
+int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn binning_alloc, void* binning_user,
+                stp_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
+                const StpSettings* settings, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* inv_viewprojmatrix,
+                const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color, int* radii, int debug,
+                void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!settings || !geometry_alloc || !binning_alloc || !image_alloc) return fail(STP_ERR_INVALID_ARGUMENT, "null settings or allocator");
+    if (P < 0 || width <= 0 || height <= 0) return fail(STP_ERR_INVALID_ARGUMENT, "bad sizes");
+    if (P == 0) return 0; // reference rasterize_points.cu:93 -- nothing launched, caller's zero image stands
+    if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !inv_viewprojmatrix || !cam_pos || !out_color)
+        return fail(STP_ERR_INVALID_ARGUMENT, "null required input");
+    if (int rc = check_settings(*settings, false)) return rc;
+    if (!colors_precomp && !shs) return fail(STP_ERR_INVALID_ARGUMENT, "neither SHs nor precomputed colours given");
+    if (!cov3D_precomp && !(scales && rotations)) return fail(STP_ERR_INVALID_ARGUMENT, "neither scale/rotation nor precomputed covariance given");
+    const bool with_inv = requires_depth_along_ray(*settings);
+    if (with_inv && !(scales && rotations)) return fail(STP_ERR_NEEDS_SCALE_ROTATION, "sorted modes need scales and rotations");
+
+    FrameParams f;
+    fill_frame(f, P, D, M, background, width, height, *settings, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+               rotations, cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered);
+
+    size_t geom_bytes = 0;
+    carve_geometry(nullptr, (size_t)P, with_inv, &geom_bytes);
+    char* geom_ptr = (char*)geometry_alloc(geometry_user, geom_bytes);
+    if (!geom_ptr) return fail(STP_ERR_ALLOC, "geometry allocator returned NULL");
+    GeometryState g = carve_geometry(geom_ptr, (size_t)P, with_inv, nullptr);
+    if (!radii) radii = g.internal_radii;
+
+    const size_t N = (size_t)width * height, T = (size_t)f.gx * f.gy;
+    size_t img_bytes = 0;
+    carve_image(nullptr, N, T, &img_bytes);
+    char* img_ptr = (char*)image_alloc(image_user, img_bytes);
+    if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
+    ImageState img = carve_image(img_ptr, N, T, nullptr);
+
+    g_timer.reset_fwd();
+    g_timer.mark(0, st);
+    STP_TRY(hipMemsetAsync(g.status, 0, 64 * sizeof(uint32_t), st), "memset status");
+    STP_TRY(launch_preprocess(f, g, radii, st), "preprocess launch");
+    STP_DEBUG_SYNC("preprocess");
+    STP_TRY(launch_scan(f, g, st), "inclusive scan");
+    STP_DEBUG_SYNC("scan");
+
+    // the one mandatory host synchronisation: num_rendered sizes the binning buffers (reference :317)
+    uint32_t host_status[2] = {0, 0};
+    STP_TRY(hipMemcpyAsync(&host_status[0], g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read num_rendered");
+    STP_TRY(hipMemcpyAsync(&host_status[1], g.status + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read status");
+    STP_TRY(hipStreamSynchronize(st), "synchronize (num_rendered)");
+    if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    const int R = (int)host_status[0];
+    g_timer.mark(1, st);
+
+    size_t bin_bytes = 0;
+    carve_binning(nullptr, (size_t)R, &bin_bytes);
+    char* bin_ptr = (char*)binning_alloc(binning_user, bin_bytes);
+    if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
+    BinningState b = carve_binning(bin_ptr, (size_t)R, nullptr);
+
+    STP_TRY(launch_duplicate(f, g, radii, b, st), "duplicate launch");
+    STP_DEBUG_SYNC("duplicate");
+    g_timer.mark(2, st);
+    STP_TRY(launch_sort(f, b, R, st), "radix sort");
+    STP_DEBUG_SYNC("sort");
+    STP_TRY(launch_ranges(f, b, img, R, st), "tile ranges");
+    STP_DEBUG_SYNC("ranges");
+    g_timer.mark(3, st);
+
+    std::string err;
+    hipError_t e = launch_render_forward(f, g, b, img, out_color, st, &err);
+    if (e != hipSuccess) {
+        if (!err.empty()) return fail(STP_ERR_QUEUE_SIZE, err);
+        return fail_hip(e, "render launch");
+    }
+    STP_DEBUG_SYNC("render");
+    g_timer.mark(4, st);
+    return R;
+}
+
+int stp_backward(int P, int D, int M, int R, const float* background, int width, int height, const StpSettings* settings,
+                 const float* means3D, const float* shs, const float* opacities, const float* colors_precomp, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* inv_viewprojmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                 const float* pixel_colors, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                 const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    if (!settings) return fail(STP_ERR_INVALID_ARGUMENT, "null settings");
+    if (P == 0) return 0; // reference rasterize_points.cu:191
+    if (int rc = check_settings(*settings, true)) return rc;
+    if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail(STP_ERR_INVALID_ARGUMENT, "null scratch buffer");
+    if (!dL_dpix || !pixel_colors || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
+        return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
+
+    FrameParams f;
+    fill_frame(f, P, D, M, background, width, height, *settings, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
+               rotations, cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, cam_pos, tan_fovx, tan_fovy, 0);
+    const bool with_inv = requires_depth_along_ray(*settings);
+    GeometryState g = carve_geometry(geom_buffer, (size_t)P, with_inv, nullptr);
+    BinningState b = carve_binning(binning_buffer, (size_t)(R > 0 ? R : 0), nullptr);
+    ImageState img = carve_image(image_buffer, (size_t)width * height, (size_t)f.gx * f.gy, nullptr);
+    if (!radii) radii = g.internal_radii;
+
+    BackwardParams bw;
+    bw.pixel_colors = pixel_colors; bw.dL_dpix = dL_dpix; bw.dL_dmean2D = dL_dmean2D; bw.dL_dconic = dL_dconic;
+    bw.dL_dopacity = dL_dopacity; bw.dL_dcolor = dL_dcolor; bw.dL_dmean3D = dL_dmean3D; bw.dL_dcov3D = dL_dcov3D; bw.dL_dsh = dL_dsh;
+    bw.dL_dscale = dL_dscale; bw.dL_drot = dL_drot;
+
+    g_timer.reset_bwd();
+    g_timer.mark(5, st);
+    std::string err;
+    hipError_t e = launch_render_backward(f, g, b, img, bw, st, &err);
+    if (e != hipSuccess) {
+        if (!err.empty()) return fail(settings->sort_mode == MODE_FULL ? STP_ERR_NO_BACKWARD : STP_ERR_QUEUE_SIZE, err);
+        return fail_hip(e, "backward render launch");
+    }
+    STP_DEBUG_SYNC("backward render");
+    g_timer.mark(6, st);
+    STP_TRY(launch_preprocess_backward(f, g, radii, bw, st), "backward preprocess launch");
+    STP_DEBUG_SYNC("backward preprocess");
+    g_timer.mark(7, st);
+    return 0;
+}
+
+int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream)
+{
+    (void)projmatrix; // reference checkFrustum only applies the view-space near test (rasterizer_impl.cu:113-128)
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(STP_ERR_INVALID_ARGUMENT, "null input");
+    STP_TRY(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream), "mark_visible launch");
+    return 0;
+}
+
+} // extern "C"

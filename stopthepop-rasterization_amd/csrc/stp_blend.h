@@ -1,0 +1,155 @@
+// stp_blend.h -- per-pixel blend state and the front-to-back gradient of one blended
+// (pixel, Gaussian) pair, shared by the k-buffer and hierarchical backward kernels.
+// Replaces the blend lambdas of reference hierarchical_render.cuh:1094-1166 and
+// resorted_render.cuh:312-392 (identical maths in both).
+#pragma once
+
+#include "stp_device.h"
+
+namespace stp {
+
+// Pointers every render kernel needs (by value in the kernarg segment).
+struct RenderArgs {
+    int W, H, gx, ty0, ty1;
+    const uint2* ranges;
+    const uint32_t* point_list;
+    const float2* means2D;
+    const float4* conic_opacity;
+    const float4* cov3D_inv;
+    const float* features; // colours, P x 3
+    const float* inv_vp;
+    const float* cam;
+    const float* bg;
+    // forward outputs
+    float* final_T;
+    uint32_t* n_contrib;
+    float* out_color;
+    // backward inputs / outputs
+    const float* pixel_colors;
+    const float* dL_dpix;
+    float* dL_dmean2D; // P x 3
+    float* dL_dconic;  // P x 4
+    float* dL_dopacity;
+    float* dL_dcolor;  // P x 3
+};
+
+struct FwdPixel {
+    float T;
+    float C[3];
+};
+
+struct BwdPixel {
+    float T_final;
+    float dL_dpix[3];
+    float final_color[3];
+    float bg_dot; // sum_ch bg[ch] * dL_dpix[ch]
+    float T;
+    float C[3];
+};
+
+__device__ __forceinline__ void init_fwd_pixel(FwdPixel& p)
+{
+    p.T = 1.0f;
+    p.C[0] = p.C[1] = p.C[2] = 0.0f;
+}
+
+__device__ __forceinline__ void init_bwd_pixel(BwdPixel& b, const RenderArgs& a, bool inside, int px, int py)
+{
+    const size_t N = (size_t)a.W * a.H;
+    const size_t pid = (size_t)a.W * py + px;
+    b.T = 1.0f;
+    b.T_final = inside ? a.final_T[pid] : 0.0f;
+    b.bg_dot = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        b.C[ch] = 0.0f;
+        b.dL_dpix[ch] = inside ? a.dL_dpix[ch * N + pid] : 0.0f;
+        b.final_color[ch] = inside ? (a.pixel_colors[ch * N + pid] - b.T_final * a.bg[ch]) : 0.0f;
+        b.bg_dot += a.bg[ch] * b.dL_dpix[ch];
+    }
+}
+
+// Forward blend of the head entry; false = pixel saturated (nothing accumulated).
+__device__ __forceinline__ bool blend_forward(FwdPixel& p, const float* __restrict__ features, int id, float alpha)
+{
+    const float test_T = p.T * (1.0f - alpha);
+    if (test_T < T_THRESHOLD) return false;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) p.C[ch] += features[3 * (size_t)id + ch] * alpha * p.T;
+    p.T = test_T;
+    return true;
+}
+
+// Gradient of one blended pair, front-to-back formulation: the colour behind the current entry is
+// reconstructed from the forward image, accum_rec = (final_colour - C_so_far) / T_after.
+// Nine fp32 atomics per pair (hardware global_atomic_add_f32; build with -munsafe-fp-atomics).
+__device__ __forceinline__ bool blend_backward(BwdPixel& b, const RenderArgs& a, int px, int py, int id, float G)
+{
+    const float4 co = a.conic_opacity[id];
+    const float alpha = fminf(0.99f, co.w * G);
+    const float test_T = b.T * (1.0f - alpha);
+    if (test_T < T_THRESHOLD) return false;
+    const float2 xy = a.means2D[id];
+    const float dx = xy.x - (float)px, dy = xy.y - (float)py;
+    const float dchannel_dcolor = alpha * b.T;
+    float dL_dalpha = 0.0f;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float c = a.features[3 * (size_t)id + ch];
+        b.C[ch] += c * alpha * b.T;
+        const float accum_rec = (b.final_color[ch] - b.C[ch]) / test_T;
+        dL_dalpha += (c - accum_rec) * b.dL_dpix[ch];
+        atomicAdd(&a.dL_dcolor[3 * (size_t)id + ch], dchannel_dcolor * b.dL_dpix[ch]);
+    }
+    dL_dalpha *= b.T;
+    dL_dalpha += (-b.T_final / (1.f - alpha)) * b.bg_dot;
+    const float dL_dG = co.w * dL_dalpha;
+    const float gdx = G * dx, gdy = G * dy;
+    const float dG_ddelx = -gdx * co.x - gdy * co.y;
+    const float dG_ddely = -gdy * co.z - gdx * co.y;
+    atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 0], dL_dG * dG_ddelx * (0.5f * (float)a.W));
+    atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 1], dL_dG * dG_ddely * (0.5f * (float)a.H));
+    atomicAdd(&a.dL_dconic[4 * (size_t)id + 0], -0.5f * gdx * dx * dL_dG);
+    atomicAdd(&a.dL_dconic[4 * (size_t)id + 1], -0.5f * gdx * dy * dL_dG);
+    atomicAdd(&a.dL_dconic[4 * (size_t)id + 3], -0.5f * gdy * dy * dL_dG);
+    atomicAdd(&a.dL_dopacity[id], G * dL_dalpha);
+    b.T = test_T;
+    return true;
+}
+
+// Per-pixel sorted insertion window in registers (reference resorted_render.cuh:74-119,186-197;
+// hierarchical_render.cuh:386-417,509-522).  All indexing is compile-time (fully unrolled) so the
+// arrays stay in VGPRs.
+template <int CAP> struct Window {
+    float depth[CAP];
+    float store[CAP];
+    int id[CAP];
+    int num;
+    __device__ __forceinline__ void init()
+    {
+        num = 0;
+#pragma unroll
+        for (int i = 0; i < CAP; i++) { depth[i] = FLT_MAX; store[i] = 0.0f; id[i] = -1; }
+    }
+    // strict '<': a new entry goes behind old entries of equal depth
+    __device__ __forceinline__ void insert(float d, int gid, float st)
+    {
+#pragma unroll
+        for (int s = 0; s < CAP; s++) {
+            const bool sw = d < depth[s];
+            const float td = depth[s]; const int ti = id[s]; const float ts = store[s];
+            depth[s] = sw ? d : td; id[s] = sw ? gid : ti; store[s] = sw ? st : ts;
+            d = sw ? td : d; gid = sw ? ti : gid; st = sw ? ts : st;
+        }
+        num++;
+    }
+    __device__ __forceinline__ void pop()
+    {
+#pragma unroll
+        for (int i = 1; i < CAP; i++) { depth[i - 1] = depth[i]; store[i - 1] = store[i]; id[i - 1] = id[i]; }
+        depth[CAP - 1] = FLT_MAX;
+        num--;
+    }
+};
+
+} // namespace stp

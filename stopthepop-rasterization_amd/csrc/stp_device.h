@@ -1,0 +1,199 @@
+// stp_device.h -- device-side leaf math and wave64 helpers shared by the gfx950 kernels.
+//
+// Numerics policy (see DESIGN.md "Numerics"): every quantity that decides a discrete outcome --
+// screen rectangles, radii, tile counts, the 64-bit sort keys, view rays and depth-along-ray keys --
+// is evaluated with floating-point contraction disabled (or with explicitly written fmaf) in a
+// fixed operation order, so tile lists and per-pixel blend orders are reproducible bit-for-bit.
+// Colour/alpha arithmetic in the blend loops is left to the compiler (it may fuse).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include <cstdint>
+
+namespace stp {
+
+constexpr float ALPHA_THRESHOLD = 1.0f / 255.0f; // reference auxiliary.h:21-22
+constexpr float T_THRESHOLD = 0.0001f;           // reference auxiliary.h:23
+constexpr uint32_t INVALID_TILE_ID = 0xFFFFFFFFu; // reference config.h:19
+
+__device__ __constant__ const float kSH_C0 = 0.28209479177387814f;
+__device__ __constant__ const float kSH_C1 = 0.4886025119029199f;
+__device__ __constant__ const float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                                 -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ const float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                                 0.3731763325901154f,  -0.4570457994644658f, 1.445305721320277f,
+                                                 -0.5900435899266435f};
+
+// ---------------------------------------------------------------- wave64 helpers
+__device__ __forceinline__ int lane_id() { return (int)__lane_id(); }
+
+// Intra-wave LDS hand-off: DS operations of one wave execute in issue order, so only the
+// compiler must be kept from reordering or caching across the hand-off.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Broadcast lane I (0..3) of every aligned group of 4 lanes (DPP quad_perm, no LDS traffic).
+template <int I> __device__ __forceinline__ int quad_bcast_i(int v)
+{
+    return __builtin_amdgcn_mov_dpp(v, I * 0x55, 0xF, 0xF, true);
+}
+template <int I> __device__ __forceinline__ float quad_bcast(float v)
+{
+    return __int_as_float(quad_bcast_i<I>(__float_as_int(v)));
+}
+__device__ __forceinline__ float quad_bcast_dyn(float v, int i)
+{
+    switch (i) {
+    case 0: return quad_bcast<0>(v);
+    case 1: return quad_bcast<1>(v);
+    case 2: return quad_bcast<2>(v);
+    default: return quad_bcast<3>(v);
+    }
+}
+
+// ---------------------------------------------------------------- small vector helpers
+struct Mat3 { float m[3][3]; }; // m[c][r]: column c, row r (same storage convention as the reference's vector library)
+
+__device__ __forceinline__ Mat3 mat_mul(const Mat3& a, const Mat3& b)
+{
+#pragma clang fp contract(off)
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = a.m[0][j] * b.m[i][0] + a.m[1][j] * b.m[i][1] + a.m[2][j] * b.m[i][2];
+    return r;
+}
+__device__ __forceinline__ Mat3 mat_transpose(const Mat3& a)
+{
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = a.m[j][i];
+    return r;
+}
+__device__ __forceinline__ Mat3 mat_diag(float a, float b, float c)
+{
+    Mat3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.m[i][j] = 0.0f;
+    r.m[0][0] = a; r.m[1][1] = b; r.m[2][2] = c;
+    return r;
+}
+
+// Rotation matrix from quaternion (r,x,y,z), the nine terms laid out as in reference
+// forward_common.h:158-169 (first three terms form column 0).
+__device__ __forceinline__ Mat3 quat_to_mat(float4 q)
+{
+#pragma clang fp contract(off)
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    Mat3 R;
+    R.m[0][0] = 1.f - 2.f * (y * y + z * z); R.m[0][1] = 2.f * (x * y - r * z);       R.m[0][2] = 2.f * (x * z + r * y);
+    R.m[1][0] = 2.f * (x * y + r * z);       R.m[1][1] = 1.f - 2.f * (x * x + z * z); R.m[1][2] = 2.f * (y * z - r * x);
+    R.m[2][0] = 2.f * (x * z - r * y);       R.m[2][1] = 2.f * (y * z + r * x);       R.m[2][2] = 1.f - 2.f * (x * x + y * y);
+    return R;
+}
+
+__device__ __forceinline__ float saturatef(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); } // NaN -> 0
+
+// reference auxiliary.h:66-69 (double arithmetic because of the double literals there)
+__device__ __forceinline__ float ndc_to_pix(float v, int S)
+{
+    return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+// reference auxiliary.h:91-101 + our tile-row window
+__device__ __forceinline__ void get_rect(float2 p, float2 ext, int gx, int gy, int ty0, int ty1, int& x0, int& y0, int& x1, int& y1)
+{
+#pragma clang fp contract(off)
+    x0 = min(gx, max(0, (int)floorf((p.x - ext.x) / 16.0f)));
+    y0 = min(gy, max(0, (int)floorf((p.y - ext.y) / 16.0f)));
+    x1 = min(gx, max(0, (int)ceilf((p.x + ext.x) / 16.0f)));
+    y1 = min(gy, max(0, (int)ceilf((p.y + ext.y) / 16.0f)));
+    y0 = max(y0, ty0);
+    y1 = min(y1, ty1);
+    if (y1 < y0) y1 = y0;
+}
+
+// Depth of the point of maximum contribution along a view ray (reference stopthepop_common.cuh:44-55).
+// p0 = [S00 S01 S02], p1 = [S11 S12 S22], p2 = Sigma^-1 (mu - cam).  Canonical evaluation order:
+// every dot product is fma(c, z, fma(b, y, a*x)); the reciprocal is the IEEE quotient 1/x.
+__device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2, float3 v)
+{
+    const float a0 = fmaf(p0.z, v.z, fmaf(p0.y, v.y, p0.x * v.x));
+    const float a1 = fmaf(p1.y, v.z, fmaf(p1.x, v.y, p0.y * v.x));
+    const float a2 = fmaf(p1.z, v.z, fmaf(p1.y, v.y, p0.z * v.x));
+    const float num = fmaf(p2.z, v.z, fmaf(p2.y, v.y, p2.x * v.x));
+    const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
+    const float rcp = 1.0f / fmaxf(0.00001f, den);
+    return num * rcp;
+}
+
+__device__ __forceinline__ float3 f4_xyz(float4 a) { return make_float3(a.x, a.y, a.z); }
+
+// reference auxiliary.h:71-81 and stopthepop_common.cuh:68-74; normalize(v) = v * (1/sqrt(v.v))
+__device__ __forceinline__ float3 view_ray(const float* __restrict__ inv, float3 cam, float px, float py, int W, int H)
+{
+#pragma clang fp contract(off)
+    const float ndcx = px * (2.0f / (float)W) - 1.0f;
+    const float ndcy = py * (2.0f / (float)H) - 1.0f;
+    float p[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) p[j] = (inv[j] * ndcx + inv[4 + j] * ndcy) + inv[12 + j];
+    const float rcp_w = 1.0f / p[3];
+    const float dx = p[0] * rcp_w - cam.x, dy = p[1] * rcp_w - cam.y, dz = p[2] * rcp_w - cam.z;
+    const float s = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    return make_float3(dx * s, dy * s, dz * s);
+}
+
+// reference stopthepop_common.cuh:76-79
+__device__ __forceinline__ float opacity_factor(float dx, float dy, float4 co)
+{
+#pragma clang fp contract(off)
+    return 0.5f * (co.x * dx * dx + co.z * dy * dy) + co.y * dx * dy;
+}
+
+// Smallest "power" (largest contribution) a Gaussian reaches inside an axis-aligned pixel rectangle
+// and where (reference stopthepop_common.cuh:130-174).  patch = rect size - 1.
+__device__ __forceinline__ float max_contrib_power_rect(float4 co, float2 mean, float2 rmin, float2 rmax,
+                                                        float patch_w, float patch_h, float2& max_pos)
+{
+#pragma clang fp contract(off)
+    const float x_min_diff = rmin.x - mean.x;
+    const float x_left = x_min_diff > 0.0f ? 1.0f : 0.0f;
+    const float not_in_x = x_left + (mean.x > rmax.x ? 1.0f : 0.0f);
+    const float y_min_diff = rmin.y - mean.y;
+    const float y_above = y_min_diff > 0.0f ? 1.0f : 0.0f;
+    const float not_in_y = y_above + (mean.y > rmax.y ? 1.0f : 0.0f);
+    max_pos = mean;
+    float power = 0.0f;
+    if ((not_in_y + not_in_x) > 0.0f) {
+        const float px = x_left * rmin.x + (1.0f - x_left) * rmax.x;
+        const float py = y_above * rmin.y + (1.0f - y_above) * rmax.y;
+        const float dx = copysignf(patch_w, x_min_diff);
+        const float dy = copysignf(patch_h, y_min_diff);
+        const float diffx = mean.x - px, diffy = mean.y - py;
+        const float rcp_x = 1.0f / (patch_w * patch_w * co.x);
+        const float rcp_y = 1.0f / (patch_h * patch_h * co.z);
+        const float tx = not_in_y * saturatef((dx * co.x * diffx + dx * co.y * diffy) * rcp_x);
+        const float ty = not_in_x * saturatef((dy * co.y * diffx + dy * co.z * diffy) * rcp_y);
+        max_pos = make_float2(px + tx * dx, py + ty * dy);
+        power = opacity_factor(mean.x - max_pos.x, mean.y - max_pos.y, co);
+    }
+    return power;
+}
+
+__device__ __forceinline__ uint64_t make_sort_key(uint32_t tile, float depth) // reference auxiliary.h:238-244
+{
+    return ((uint64_t)tile << 32) | (uint64_t)__float_as_uint(depth);
+}
+
+} // namespace stp

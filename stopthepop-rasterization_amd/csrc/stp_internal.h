@@ -1,0 +1,135 @@
+// stp_internal.h -- host-side internals of libstp_raster.so: scratch-buffer carving and the
+// launcher interface between the C ABI (stp_api.hip) and the kernel translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <string>
+
+#include "../../include/stp_raster.h"
+
+namespace stp {
+
+constexpr int TILE = 16;
+constexpr size_t ALIGN = 256; // sub-array alignment inside the scratch buffers
+
+enum SortMode { MODE_GLOBAL = 0, MODE_FULL = 1, MODE_KBUFFER = 2, MODE_HIER = 3 };
+enum SortOrder { ORDER_Z = 0, ORDER_DISTANCE = 1, ORDER_PTD_CENTER = 2, ORDER_PTD_MAX = 3 };
+
+inline bool requires_depth_along_ray(const StpSettings& s) // reference rasterizer.h:66-71
+{
+    return s.sort_mode != MODE_GLOBAL || s.sort_order == ORDER_PTD_CENTER || s.sort_order == ORDER_PTD_MAX;
+}
+
+// Bump allocator over one byte buffer: the counterpart of the reference's obtain()/required()
+// (rasterizer_impl.h:21-27,68-75) with our own layout.  With base == nullptr it only measures.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    template <typename T> T* take(size_t count, size_t* off_out = nullptr)
+    {
+        off = (off + ALIGN - 1) & ~(ALIGN - 1);
+        if (off_out) *off_out = off;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t total() const { return ((off + ALIGN - 1) & ~(ALIGN - 1)) + ALIGN; }
+};
+
+// Per-Gaussian state (reference GeometryState, rasterizer_impl.cu:175-193).  SoA, HBM-resident
+// between forward and backward.
+struct GeometryState {
+    uint32_t* status;        // [0] num_rendered, [1] error flags   (read back once per forward)
+    float* depths;           // P
+    uint8_t* clamped;        // 3P
+    int32_t* internal_radii; // P
+    float2* rects2D;         // P
+    float2* means2D;         // P
+    float* cov3D;            // 6P
+    float4* cov3D_inv;       // 3P, only if requires_depth_along_ray
+    float4* conic_opacity;   // P
+    float* rgb;              // 3P
+    uint32_t* tiles_touched; // P
+    uint32_t* point_offsets; // P
+    char* scan_temp;
+    size_t scan_temp_bytes;
+};
+
+struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges sized per tile, not per pixel)
+    float* final_T;      // N
+    uint32_t* n_contrib; // N
+    uint2* ranges;       // T
+};
+
+struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
+    uint32_t* point_list;
+    uint32_t* point_list_unsorted;
+    uint64_t* keys;
+    uint64_t* keys_unsorted;
+    char* sort_temp;
+    size_t sort_temp_bytes;
+};
+
+struct NamedOffset { const char* name; size_t offset; size_t count; };
+
+GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
+ImageState carve_image(char* base, size_t N, size_t T, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
+BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
+
+size_t scan_temp_bytes(size_t P);
+size_t sort_temp_bytes(size_t R);
+
+// Everything a kernel launcher needs about one frame.
+struct FrameParams {
+    int P, D, M, W, H, gx, gy;
+    int ty0, ty1; // tile-row window
+    float focal_x, focal_y, tan_fovx, tan_fovy, scale_modifier;
+    StpSettings s;
+    const float* background;
+    const float* means3D;
+    const float* shs;
+    const float* colors_precomp;
+    const float* opacities;
+    const float* scales;
+    const float* rotations;
+    const float* cov3D_precomp;
+    const float* viewmatrix;
+    const float* projmatrix;
+    const float* inv_viewprojmatrix;
+    const float* cam_pos;
+    int prefiltered;
+};
+
+struct BackwardParams {
+    const float* pixel_colors;
+    const float* dL_dpix;
+    float* dL_dmean2D;
+    float* dL_dconic;
+    float* dL_dopacity;
+    float* dL_dcolor;
+    float* dL_dmean3D;
+    float* dL_dcov3D;
+    float* dL_dsh;
+    float* dL_dscale;
+    float* dL_drot;
+};
+
+// ---- launchers (one per stage; each returns hipSuccess or the launch error) ----
+hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, hipStream_t st);
+hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, hipStream_t st);
+hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, hipStream_t st);
+hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st);
+hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
+                                 float* out_color, hipStream_t st, std::string* err);
+hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
+                                  const BackwardParams& bw, hipStream_t st, std::string* err);
+hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState& g, const int* radii, const BackwardParams& bw, hipStream_t st);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t st);
+
+uint32_t higher_msb(uint32_t n);
+
+} // namespace stp

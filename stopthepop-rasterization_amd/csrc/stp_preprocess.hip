@@ -1,0 +1,370 @@
+// stp_preprocess.hip -- per-Gaussian forward stage, tile-key emission, tile ranges, visibility.
+//
+// Replaces (reference file:line under cuda_rasterizer/):
+//   preprocessCUDA<3,TBC,LB>              forward.cu:68-229      -> preprocess_kernel
+//   duplicateWithKeysCUDA                 forward.cu:25-65       \  duplicate_kernel (one kernel; the
+//   duplicateWithKeys_extended<...>       stopthepop_common.cuh:324-621 /  options are runtime-uniform)
+//   identifyTileRanges                    rasterizer_impl.cu:133-158 -> tile_ranges_kernel
+//   checkFrustum                          rasterizer_impl.cu:113-128 -> mark_visible_kernel
+//
+// All four are HBM-streaming kernels: one thread per Gaussian (or per sorted duplicate), inputs
+// read once with the widest loads the layout allows, SoA outputs written once.  Load balancing
+// (the reference's warp-cooperative handling of Gaussians with > 32 tiles) only changes speed,
+// never results; here every Gaussian's tile loop is per-thread.
+#include "stp_internal.h"
+#include "stp_device.h"
+
+namespace stp {
+
+namespace {
+
+// Everything the preprocess kernel needs, by value (kernarg segment; no constant-memory upload).
+struct PreArgs {
+    int P, D, M, W, H, gx, gy, ty0, ty1;
+    float focal_x, focal_y, tan_fovx, tan_fovy, scale_modifier;
+    int sort_order, rect_bounding, tight_opacity_bounding, tile_based_culling, proper_ewa_scaling, prefiltered;
+    const float* means3D;
+    const float* scales;
+    const float* rotations;
+    const float* opacities;
+    const float* shs;
+    const float* cov3D_precomp;
+    const float* colors_precomp;
+    const float* view;
+    const float* proj;
+    const float* cam;
+    int* radii;
+    GeometryState g;
+};
+
+// SH -> RGB, reference forward_common.h:20-70 (same association of the sums)
+__device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, float3 mean, float3 cam, const float* __restrict__ shs,
+                                          uint8_t* __restrict__ clamped, float* __restrict__ rgb)
+{
+#pragma clang fp contract(off)
+    float dx = mean.x - cam.x, dy = mean.y - cam.y, dz = mean.z - cam.z;
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / len, y = dy / len, z = dz / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float res[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) res[ch] = kSH_C0 * sh[ch];
+    if (deg > 0) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++)
+            res[ch] = res[ch] - (kSH_C1 * y) * sh[3 + ch] + (kSH_C1 * z) * sh[6 + ch] - (kSH_C1 * x) * sh[9 + ch];
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++)
+                res[ch] = res[ch] + (kSH_C2[0] * xy) * sh[12 + ch] + (kSH_C2[1] * yz) * sh[15 + ch] +
+                          (kSH_C2[2] * (2.0f * zz - xx - yy)) * sh[18 + ch] + (kSH_C2[3] * xz) * sh[21 + ch] +
+                          (kSH_C2[4] * (xx - yy)) * sh[24 + ch];
+            if (deg > 2) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++)
+                    res[ch] = res[ch] + (kSH_C3[0] * y * (3.0f * xx - yy)) * sh[27 + ch] + (kSH_C3[1] * xy * z) * sh[30 + ch] +
+                              (kSH_C3[2] * y * (4.0f * zz - xx - yy)) * sh[33 + ch] +
+                              (kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy)) * sh[36 + ch] +
+                              (kSH_C3[4] * x * (4.0f * zz - xx - yy)) * sh[39 + ch] + (kSH_C3[5] * z * (xx - yy)) * sh[42 + ch] +
+                              (kSH_C3[6] * x * (xx - 3.0f * yy)) * sh[45 + ch];
+            }
+        }
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float r = res[ch] + 0.5f;
+        clamped[3 * (size_t)idx + ch] = (r < 0.0f) ? 1 : 0;
+        rgb[3 * (size_t)idx + ch] = fmaxf(r, 0.0f);
+    }
+}
+
+__global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P) return;
+    a.radii[idx] = 0;
+    a.g.tiles_touched[idx] = 0;
+
+    const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
+    const float* __restrict__ view = a.view;
+    // view-space position; near culling at z <= 0.2 (reference auxiliary.h:211-236)
+    float3 pv;
+    pv.x = view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12] * 1.0f;
+    pv.y = view[1] * mean.x + view[5] * mean.y + view[9] * mean.z + view[13] * 1.0f;
+    pv.z = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14] * 1.0f;
+    if (pv.z <= 0.2f) {
+        if (a.prefiltered) atomicOr(&a.g.status[1], 1u);
+        return;
+    }
+
+    // 3D covariance (reference forward_common.h:149-183) or the precomputed one
+    float c3[6];
+    if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+    } else {
+        const float3 sc = make_float3(a.scales[3 * (size_t)idx], a.scales[3 * (size_t)idx + 1], a.scales[3 * (size_t)idx + 2]);
+        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const Mat3 S = mat_diag(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
+        const Mat3 Mm = mat_mul(S, quat_to_mat(q));
+        const Mat3 Sig = mat_mul(mat_transpose(Mm), Mm);
+        c3[0] = Sig.m[0][0]; c3[1] = Sig.m[0][1]; c3[2] = Sig.m[0][2]; c3[3] = Sig.m[1][1]; c3[4] = Sig.m[1][2]; c3[5] = Sig.m[2][2];
+#pragma unroll
+        for (int k = 0; k < 6; k++) a.g.cov3D[6 * (size_t)idx + k] = c3[k];
+    }
+
+    // EWA projection to a 2D covariance (reference forward_common.h:73-106)
+    float3 t = pv;
+    const float limx = 1.3f * a.tan_fovx, limy = 1.3f * a.tan_fovy;
+    const float txtz = t.x / t.z, tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+    Mat3 J;
+    J.m[0][0] = a.focal_x / t.z; J.m[0][1] = 0.0f;              J.m[0][2] = -(a.focal_x * t.x) / (t.z * t.z);
+    J.m[1][0] = 0.0f;              J.m[1][1] = a.focal_y / t.z; J.m[1][2] = -(a.focal_y * t.y) / (t.z * t.z);
+    J.m[2][0] = 0.0f;              J.m[2][1] = 0.0f;              J.m[2][2] = 0.0f;
+    Mat3 Wv;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) Wv.m[i][j] = view[4 * i + j];
+    const Mat3 T = mat_mul(mat_transpose(Wv), J);
+    Mat3 Vrk;
+    Vrk.m[0][0] = c3[0]; Vrk.m[0][1] = c3[1]; Vrk.m[0][2] = c3[2];
+    Vrk.m[1][0] = c3[1]; Vrk.m[1][1] = c3[3]; Vrk.m[1][2] = c3[4];
+    Vrk.m[2][0] = c3[2]; Vrk.m[2][1] = c3[4]; Vrk.m[2][2] = c3[5];
+    const Mat3 cov = mat_mul(mat_mul(mat_transpose(T), mat_transpose(Vrk)), T);
+
+    // low-pass dilation, optional Mip-Splatting opacity scaling (reference forward_common.h:108-131)
+    const float opacity = a.opacities[idx];
+    float c2x = cov.m[0][0], c2y = cov.m[0][1], c2z = cov.m[1][1];
+    c2x += 0.3f; c2z += 0.3f;
+    const float det = c2x * c2z - c2y * c2y;
+    float conv_scale = 1.0f;
+    if (a.proper_ewa_scaling) {
+        const float det_orig = cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1];
+        conv_scale = sqrtf(fmaxf(0.000025f, det_orig / det));
+    }
+    if (det == 0.0f) return;
+    const float det_inv = 1.f / det;
+    const float4 co = make_float4(c2z * det_inv, -c2y * det_inv, c2x * det_inv, opacity * conv_scale);
+    if (co.w < ALPHA_THRESHOLD) return;
+
+    // screen-space extent (reference forward.cu:151-164)
+    const float thr = logf(co.w / ALPHA_THRESHOLD);
+    const float extent = a.tight_opacity_bounding ? (float)fmin(3.33, (double)sqrtf(2.0f * thr)) : 3.33f;
+    const float mid = 0.5f * (c2x + c2z);
+    const float lambda = mid + sqrtf(fmaxf(0.01f, mid * mid - det));
+    const float radius = extent * sqrtf(lambda);
+    if (radius <= 0.0f) return;
+
+    // projection of the mean (reference auxiliary.h:83-90; the 4x4 product sums (m0 x + m1 y) + (m2 z + m3 w))
+    const float* __restrict__ proj = a.proj;
+    float ph[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) ph[j] = (proj[j] * mean.x + proj[4 + j] * mean.y) + (proj[8 + j] * mean.z + proj[12 + j] * 1.0f);
+    const float p_w = 1.0f / (ph[3] + 0.0000001f);
+    const float2 mean2D = make_float2(ndc_to_pix(ph[0] * p_w, a.W), ndc_to_pix(ph[1] * p_w, a.H));
+
+    const float ext_x = fminf(a.rect_bounding ? (extent * sqrtf(c2x)) : radius, radius);
+    const float ext_y = fminf(a.rect_bounding ? (extent * sqrtf(c2z)) : radius, radius);
+    const float2 rect_dims = make_float2(ext_x, ext_y);
+    int x0, y0, x1, y1;
+    get_rect(mean2D, rect_dims, a.gx, a.gy, a.ty0, a.ty1, x0, y0, x1, y1);
+    const int rect_tiles = (x1 - x0) * (y1 - y0);
+    if (rect_tiles == 0) return;
+
+    int tile_count = rect_tiles;
+    if (a.tile_based_culling) { // reference stopthepop_common.cuh:176-262
+        tile_count = 0;
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
+                const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
+                float2 mp;
+                const float f = max_contrib_power_rect(co, mean2D, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), mp);
+                tile_count += (f <= thr) ? 1 : 0;
+            }
+    }
+    if (tile_count == 0) return;
+
+    const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
+    if (a.colors_precomp == nullptr) sh_to_rgb(idx, a.D, a.M, mean, cam, a.shs, a.g.clamped, a.g.rgb);
+
+    if (a.g.cov3D_inv != nullptr) { // reference forward.cu:208-220, stopthepop_common.cuh:13-41
+        const float3 sc = make_float3(a.scales[3 * (size_t)idx], a.scales[3 * (size_t)idx + 1], a.scales[3 * (size_t)idx + 2]);
+        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const Mat3 S = mat_diag(1.f / (a.scale_modifier * fmaxf(1e-3f, sc.x)), 1.f / (a.scale_modifier * fmaxf(1e-3f, sc.y)),
+                                1.f / (a.scale_modifier * fmaxf(1e-3f, sc.z)));
+        const Mat3 Mm = mat_mul(S, quat_to_mat(q));
+        const Mat3 inv = mat_mul(mat_transpose(Mm), Mm);
+        const float dx = cam.x - mean.x, dy = cam.y - mean.y, dz = cam.z - mean.z;
+        const float ux = (-inv.m[0][0]) * dx + (-inv.m[1][0]) * dy + (-inv.m[2][0]) * dz;
+        const float uy = (-inv.m[0][1]) * dx + (-inv.m[1][1]) * dy + (-inv.m[2][1]) * dz;
+        const float uz = (-inv.m[0][2]) * dx + (-inv.m[1][2]) * dy + (-inv.m[2][2]) * dz;
+        a.g.cov3D_inv[3 * (size_t)idx + 0] = make_float4(inv.m[0][0], inv.m[0][1], inv.m[0][2], 0.0f);
+        a.g.cov3D_inv[3 * (size_t)idx + 1] = make_float4(inv.m[1][1], inv.m[1][2], inv.m[2][2], 0.0f);
+        a.g.cov3D_inv[3 * (size_t)idx + 2] = make_float4(ux, uy, uz, 0.0f);
+    }
+
+    float depth;
+    if (a.sort_order == ORDER_Z) depth = pv.z;
+    else {
+        const float dx = cam.x - mean.x, dy = cam.y - mean.y, dz = cam.z - mean.z;
+        depth = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    a.g.depths[idx] = depth;
+    a.radii[idx] = (int)ceilf(radius);
+    a.g.rects2D[idx] = rect_dims;
+    a.g.means2D[idx] = mean2D;
+    a.g.conic_opacity[idx] = co;
+    a.g.tiles_touched[idx] = (uint32_t)tile_count;
+}
+
+struct DupArgs {
+    int P, W, H, gx, gy, ty0, ty1;
+    int sort_order, tile_based_culling;
+    const float* inv_vp;
+    const float* cam;
+    const int* radii;
+    GeometryState g;
+    uint64_t* keys;
+    uint32_t* values;
+};
+
+__global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= a.P) return;
+    if (a.radii[idx] <= 0) return;
+    uint32_t off = (idx == 0) ? 0u : a.g.point_offsets[idx - 1];
+    const uint32_t off_to = a.g.point_offsets[idx];
+    const float2 xy = a.g.means2D[idx];
+    const float2 ext = a.g.rects2D[idx];
+    int x0, y0, x1, y1;
+    get_rect(xy, ext, a.gx, a.gy, a.ty0, a.ty1, x0, y0, x1, y1);
+
+    const bool tbc = a.tile_based_culling != 0;
+    const bool per_tile_depth = a.sort_order == ORDER_PTD_CENTER || a.sort_order == ORDER_PTD_MAX;
+    const bool eval_max = tbc || a.sort_order == ORDER_PTD_MAX;
+    float4 co = make_float4(0, 0, 0, 0);
+    float thr = 0.0f;
+    if (eval_max) {
+        co = a.g.conic_opacity[idx];
+        thr = logf(co.w / ALPHA_THRESHOLD);
+    }
+    float3 p0 = make_float3(0, 0, 0), p1 = p0, p2 = p0, cam = p0;
+    if (per_tile_depth) {
+        p0 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 0]);
+        p1 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 1]);
+        p2 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 2]);
+        cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
+    }
+    const float global_depth = a.g.depths[idx];
+
+    for (int y = y0; y < y1; y++)
+        for (int x = x0; x < x1; x++) {
+            const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
+            const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
+            float2 max_pos = make_float2(0, 0);
+            float max_fac = 0.0f;
+            if (eval_max) max_fac = max_contrib_power_rect(co, xy, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), max_pos);
+            float depth = global_depth;
+            if (per_tile_depth) { // reference stopthepop_common.cuh:439-449
+                const float2 center = make_float2((tmin.x + tmax.x) * 0.5f, (tmin.y + tmax.y) * 0.5f);
+                const float2 target = (a.sort_order == ORDER_PTD_MAX) ? max_pos : center;
+                const float3 dir = view_ray(a.inv_vp, cam, target.x, target.y, a.W, a.H);
+                depth = fmaxf(0.0f, depth_along_ray(p0, p1, p2, dir) + 8.0f);
+            }
+            const bool write = !tbc || max_fac <= thr;
+            if (write) {
+                if (off < off_to) {
+                    a.values[off] = (uint32_t)idx;
+                    a.keys[off] = make_sort_key((uint32_t)(y * a.gx + x), depth);
+                }
+                off++;
+            }
+        }
+    // pad what the (slightly more generous) preprocess count reserved but culling did not use
+    // (reference stopthepop_common.cuh:503-508, 614-619)
+    for (; off < off_to; off++) {
+        a.values[off] = 0xFFFFFFFFu;
+        a.keys[off] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
+    }
+}
+
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges, uint32_t T)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    const bool valid = cur != INVALID_TILE_ID && cur < T;
+    if (idx == 0) {
+        if (valid) ranges[cur].x = 0;
+    } else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) {
+            if (prev < T) ranges[prev].y = (uint32_t)idx;
+            if (valid) ranges[cur].x = (uint32_t)idx;
+        }
+    }
+    if (idx == L - 1 && valid) ranges[cur].y = (uint32_t)L;
+}
+
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= P) return;
+    const float z = view[2] * means3D[3 * (size_t)idx] + view[6] * means3D[3 * (size_t)idx + 1] + view[10] * means3D[3 * (size_t)idx + 2] + view[14] * 1.0f;
+    present[idx] = z > 0.2f ? 1 : 0;
+}
+
+} // namespace
+
+hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, hipStream_t st)
+{
+    PreArgs a;
+    a.P = f.P; a.D = f.D; a.M = f.M; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
+    a.focal_x = f.focal_x; a.focal_y = f.focal_y; a.tan_fovx = f.tan_fovx; a.tan_fovy = f.tan_fovy; a.scale_modifier = f.scale_modifier;
+    a.sort_order = f.s.sort_order; a.rect_bounding = f.s.rect_bounding; a.tight_opacity_bounding = f.s.tight_opacity_bounding;
+    a.tile_based_culling = f.s.tile_based_culling; a.proper_ewa_scaling = f.s.proper_ewa_scaling; a.prefiltered = f.prefiltered;
+    a.means3D = f.means3D; a.scales = f.scales; a.rotations = f.rotations; a.opacities = f.opacities; a.shs = f.shs;
+    a.cov3D_precomp = f.cov3D_precomp; a.colors_precomp = f.colors_precomp; a.view = f.viewmatrix; a.proj = f.projmatrix; a.cam = f.cam_pos;
+    a.radii = radii; a.g = g;
+    hipLaunchKernelGGL(preprocess_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, hipStream_t st)
+{
+    DupArgs a;
+    a.P = f.P; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
+    a.sort_order = f.s.sort_order; a.tile_based_culling = f.s.tile_based_culling;
+    a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.radii = radii; a.g = g; a.keys = b.keys_unsorted; a.values = b.point_list_unsorted;
+    hipLaunchKernelGGL(duplicate_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st)
+{
+    const size_t T = (size_t)f.gx * f.gy;
+    hipError_t e = hipMemsetAsync(img.ranges, 0, T * sizeof(uint2), st); // reference rasterizer_impl.cu:354
+    if (e != hipSuccess) return e;
+    if (R > 0) {
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, b.keys, img.ranges, (uint32_t)T);
+        e = hipGetLastError();
+    }
+    return e;
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t st)
+{
+    hipLaunchKernelGGL(mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, means3D, viewmatrix, present);
+    return hipGetLastError();
+}
+
+} // namespace stp

@@ -1,0 +1,392 @@
+// stp_render_tile.hip -- "one thread per pixel, tile list streamed through LDS" render kernels.
+//
+// Replaces (reference file:line under cuda_rasterizer/):
+//   renderCUDA<3,false>            forward.cu:234-366            -> render_global_fwd_kernel
+//   renderCUDA<3>  (backward)      backward.cu:437-595           -> render_global_bwd_kernel
+//   renderkBufferCUDA<3,W,false>   stopthepop/resorted_render.cuh:17-221  -> render_kbuffer_kernel<W,false>
+//   renderkBufferBackwardCUDA<3,W> stopthepop/resorted_render.cuh:223-471 -> render_kbuffer_kernel<W,true>
+//   renderSortedFullCUDA<3,false>  stopthepop/resorted_render.cuh:474-675 -> render_full_fwd_kernel
+//
+// Layout: one 256-thread workgroup (4 wave64) per 16x16 tile; the tile's (tile,depth)-sorted list is
+// staged 256 entries at a time into LDS with one coalesced id load + one gather per thread, then
+// every lane walks the staged batch with broadcast LDS reads (all lanes look at entry j together).
+// In GLOBAL backward all 64 lanes of a wave hold the SAME Gaussian at every step, so the nine
+// gradient terms are reduced across the wave with DPP and leave as nine atomics per wave instead
+// of 9 x 64.
+#include "stp_internal.h"
+#include "stp_blend.h"
+
+namespace stp {
+
+namespace {
+
+constexpr int BLOCK = 256;
+
+// XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give every XCD
+// a contiguous run of tiles -- neighbouring tiles share Gaussians, which then hit in that XCD's L2.
+__device__ __forceinline__ int remap_tile(int wg, int n_wg)
+{
+    const int q = n_wg >> 3, r = n_wg & 7;
+    const int xcd = wg & 7, k = wg >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// Sum over the 64 lanes of a wave; result valid in every lane (uniform).
+__device__ __forceinline__ float wave_sum(float v)
+{
+    int t;
+    t = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true); v += __int_as_float(t);  // quad_perm [1,0,3,2]
+    t = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true); v += __int_as_float(t);  // quad_perm [2,3,0,1]
+    t = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true); v += __int_as_float(t); // row_half_mirror
+    t = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true); v += __int_as_float(t); // row_mirror
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
+struct TileCtx {
+    int tile, tx, ty, px, py;
+    bool inside;
+    uint2 range;
+};
+
+__device__ __forceinline__ TileCtx tile_ctx(const RenderArgs& a)
+{
+    TileCtx c;
+    const int rows = a.ty1 - a.ty0;
+    const int t = remap_tile((int)blockIdx.x, a.gx * rows);
+    c.tx = t % a.gx;
+    c.ty = a.ty0 + t / a.gx;
+    c.tile = c.ty * a.gx + c.tx;
+    c.px = c.tx * TILE + (threadIdx.x & 15);
+    c.py = c.ty * TILE + (threadIdx.x >> 4);
+    c.inside = c.px < a.W && c.py < a.H;
+    c.range = a.ranges[c.tile];
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GLOBAL forward
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderArgs a)
+{
+    __shared__ float2 s_xy[BLOCK];
+    __shared__ float4 s_co[BLOCK];
+    __shared__ float s_col[3][BLOCK];
+
+    const TileCtx c = tile_ctx(a);
+    const float pxf = (float)c.px, pyf = (float)c.py;
+    bool done = !c.inside;
+    const int total = (int)(c.range.y - c.range.x);
+    const int rounds = (total + BLOCK - 1) / BLOCK;
+    int todo = total;
+
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t contributor = 0, last_contributor = 0;
+
+    for (int i = 0; i < rounds; i++, todo -= BLOCK) {
+        if (__syncthreads_and(done)) break;
+        const int progress = i * BLOCK + (int)threadIdx.x;
+        if ((int)c.range.x + progress < (int)c.range.y) {
+            const int id = (int)a.point_list[c.range.x + progress];
+            s_xy[threadIdx.x] = a.means2D[id];
+            s_co[threadIdx.x] = a.conic_opacity[id];
+            s_col[0][threadIdx.x] = a.features[3 * (size_t)id + 0];
+            s_col[1][threadIdx.x] = a.features[3 * (size_t)id + 1];
+            s_col[2][threadIdx.x] = a.features[3 * (size_t)id + 2];
+        }
+        __syncthreads();
+        const int n = min(BLOCK, todo);
+        for (int j = 0; !done && j < n; j++) {
+            contributor++;
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float alpha = fminf(0.99f, co.w * expf(power));
+            if (alpha < ALPHA_THRESHOLD) continue;
+            const float test_T = T * (1 - alpha);
+            if (test_T < T_THRESHOLD) { done = true; continue; }
+            C0 += s_col[0][j] * alpha * T;
+            C1 += s_col[1][j] * alpha * T;
+            C2 += s_col[2][j] * alpha * T;
+            T = test_T;
+            last_contributor = contributor;
+        }
+    }
+    if (c.inside) {
+        const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * c.py + c.px;
+        a.final_T[pid] = T;
+        a.n_contrib[pid] = last_contributor;
+        a.out_color[pid] = C0 + T * a.bg[0];
+        a.out_color[N + pid] = C1 + T * a.bg[1];
+        a.out_color[2 * N + pid] = C2 + T * a.bg[2];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GLOBAL backward: back-to-front with the stored n_contrib / final_T
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderArgs a)
+{
+    __shared__ int s_id[BLOCK];
+    __shared__ float2 s_xy[BLOCK];
+    __shared__ float4 s_co[BLOCK];
+    __shared__ float s_col[3][BLOCK];
+
+    const TileCtx c = tile_ctx(a);
+    const float pxf = (float)c.px, pyf = (float)c.py;
+    const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * c.py + c.px;
+    const int total = (int)(c.range.y - c.range.x);
+    const int rounds = (total + BLOCK - 1) / BLOCK;
+    int todo = total;
+
+    const float T_final = c.inside ? a.final_T[pid] : 0.0f;
+    float T = T_final;
+    uint32_t contributor = (uint32_t)total;
+    const uint32_t last_contributor = c.inside ? a.n_contrib[pid] : 0u;
+    float accum_rec[3] = {0, 0, 0}, last_color[3] = {0, 0, 0}, dL_dpixel[3] = {0, 0, 0};
+    float last_alpha = 0.0f;
+    if (c.inside)
+        for (int ch = 0; ch < 3; ch++) dL_dpixel[ch] = a.dL_dpix[ch * N + pid];
+    const float bg_dot = a.bg[0] * dL_dpixel[0] + a.bg[1] * dL_dpixel[1] + a.bg[2] * dL_dpixel[2];
+    const float ddelx_dx = 0.5f * (float)a.W, ddely_dy = 0.5f * (float)a.H;
+    const int lane = lane_id();
+
+    for (int i = 0; i < rounds; i++, todo -= BLOCK) {
+        __syncthreads();
+        const int progress = i * BLOCK + (int)threadIdx.x;
+        if ((int)c.range.x + progress < (int)c.range.y) {
+            const int id = (int)a.point_list[c.range.y - progress - 1];
+            s_id[threadIdx.x] = id;
+            s_xy[threadIdx.x] = a.means2D[id];
+            s_co[threadIdx.x] = a.conic_opacity[id];
+            s_col[0][threadIdx.x] = a.features[3 * (size_t)id + 0];
+            s_col[1][threadIdx.x] = a.features[3 * (size_t)id + 1];
+            s_col[2][threadIdx.x] = a.features[3 * (size_t)id + 2];
+        }
+        __syncthreads();
+        const int n = min(BLOCK, todo);
+        for (int j = 0; j < n; j++) {
+            // every lane steps through the same entry; lanes that skip contribute zeros to the reduction
+            contributor--;
+            bool use = c.inside && contributor < last_contributor;
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            use = use && !(power > 0.0f);
+            const float G = expf(power);
+            const float alpha = fminf(0.99f, co.w * G);
+            use = use && !(alpha < ALPHA_THRESHOLD);
+            if (!__any(use)) continue;
+
+            float g_col[3] = {0, 0, 0}, g_mx = 0, g_my = 0, g_cxx = 0, g_cxy = 0, g_cyy = 0, g_op = 0;
+            if (use) {
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                float dL_dalpha = 0.0f;
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    const float col = s_col[ch][j];
+                    accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                    last_color[ch] = col;
+                    dL_dalpha += (col - accum_rec[ch]) * dL_dpixel[ch];
+                    g_col[ch] = dchannel_dcolor * dL_dpixel[ch];
+                }
+                dL_dalpha *= T;
+                last_alpha = alpha;
+                dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = co.w * dL_dalpha;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * co.x - gdy * co.y;
+                const float dG_ddely = -gdy * co.z - gdx * co.y;
+                g_mx = dL_dG * dG_ddelx * ddelx_dx;
+                g_my = dL_dG * dG_ddely * ddely_dy;
+                g_cxx = -0.5f * gdx * dx * dL_dG;
+                g_cxy = -0.5f * gdx * dy * dL_dG;
+                g_cyy = -0.5f * gdy * dy * dL_dG;
+                g_op = G * dL_dalpha;
+            }
+            const float r0 = wave_sum(g_col[0]), r1 = wave_sum(g_col[1]), r2 = wave_sum(g_col[2]);
+            const float r3 = wave_sum(g_mx), r4 = wave_sum(g_my), r5 = wave_sum(g_cxx), r6 = wave_sum(g_cxy), r7 = wave_sum(g_cyy);
+            const float r8 = wave_sum(g_op);
+            if (lane < 9) {
+                const int id = s_id[j];
+                float v = r0; float* dst = &a.dL_dcolor[3 * (size_t)id];
+                switch (lane) {
+                case 1: v = r1; dst = &a.dL_dcolor[3 * (size_t)id + 1]; break;
+                case 2: v = r2; dst = &a.dL_dcolor[3 * (size_t)id + 2]; break;
+                case 3: v = r3; dst = &a.dL_dmean2D[3 * (size_t)id]; break;
+                case 4: v = r4; dst = &a.dL_dmean2D[3 * (size_t)id + 1]; break;
+                case 5: v = r5; dst = &a.dL_dconic[4 * (size_t)id]; break;
+                case 6: v = r6; dst = &a.dL_dconic[4 * (size_t)id + 1]; break;
+                case 7: v = r7; dst = &a.dL_dconic[4 * (size_t)id + 3]; break;
+                case 8: v = r8; dst = &a.dL_dopacity[id]; break;
+                default: break;
+                }
+                atomicAdd(dst, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PPX_KBUFFER forward / backward: per-pixel sorted window keyed by depth along the pixel's own ray
+// ------------------------------------------------------------------------------------------------
+template <int WIN, bool BACKWARD>
+__global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs a)
+{
+    __shared__ int s_id[BLOCK];
+    __shared__ float2 s_xy[BLOCK];
+    __shared__ float4 s_co[BLOCK];
+    __shared__ float4 s_inv[3][BLOCK];
+
+    const TileCtx c = tile_ctx(a);
+    const float pxf = (float)c.px, pyf = (float)c.py;
+    bool done = !c.inside;
+    const int total = (int)(c.range.y - c.range.x);
+    const int rounds = (total + BLOCK - 1) / BLOCK;
+    int todo = total;
+
+    const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
+    const float3 dir = view_ray(a.inv_vp, cam, pxf, pyf, a.W, a.H);
+
+    Window<WIN> win;
+    win.init();
+    FwdPixel fp;
+    BwdPixel bp;
+    if constexpr (BACKWARD) init_bwd_pixel(bp, a, c.inside, c.px, c.py);
+    else init_fwd_pixel(fp);
+    uint32_t contributor = 0;
+
+    auto blend_one = [&]() {
+        if (win.num == 0) return;
+        bool ok;
+        if constexpr (BACKWARD) ok = blend_backward(bp, a, c.px, c.py, win.id[0], win.store[0]);
+        else ok = blend_forward(fp, a.features, win.id[0], win.store[0]);
+        if (!ok) { win.num--; done = true; return; }
+        win.pop();
+    };
+
+    for (int i = 0; i < rounds; i++, todo -= BLOCK) {
+        if (__syncthreads_and(done)) break;
+        const int progress = i * BLOCK + (int)threadIdx.x;
+        if ((int)c.range.x + progress < (int)c.range.y) {
+            const int id = (int)a.point_list[c.range.x + progress];
+            s_id[threadIdx.x] = id;
+            s_xy[threadIdx.x] = a.means2D[id];
+            s_co[threadIdx.x] = a.conic_opacity[id];
+            s_inv[0][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 0];
+            s_inv[1][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 1];
+            s_inv[2][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 2];
+        }
+        __syncthreads();
+        const int n = min(BLOCK, todo);
+        for (int j = 0; !done && j < n; j++) {
+            if (win.num == WIN) blend_one(); // before the next candidate is looked at
+            if (done) break;
+            contributor++;
+            const float2 xy = s_xy[j];
+            const float4 co = s_co[j];
+            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            if (power > 0.0f) continue;
+            const float G = expf(power);
+            const float alpha = fminf(0.99f, co.w * G);
+            if (alpha < ALPHA_THRESHOLD) continue;
+            const float depth = depth_along_ray(f4_xyz(s_inv[0][j]), f4_xyz(s_inv[1][j]), f4_xyz(s_inv[2][j]), dir);
+            if (depth < 0.0f) continue;
+            win.insert(depth, s_id[j], BACKWARD ? G : alpha);
+        }
+    }
+    if (!done)
+        while (win.num > 0 && !done) blend_one();
+
+    if constexpr (!BACKWARD) {
+        if (c.inside) {
+            const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * c.py + c.px;
+            a.final_T[pid] = fp.T;
+            a.n_contrib[pid] = contributor;
+            a.out_color[pid] = fp.C[0] + fp.T * a.bg[0];
+            a.out_color[N + pid] = fp.C[1] + fp.T * a.bg[1];
+            a.out_color[2 * N + pid] = fp.C[2] + fp.T * a.bg[2];
+        }
+    }
+}
+
+} // namespace
+
+static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img)
+{
+    RenderArgs a{};
+    a.W = f.W; a.H = f.H; a.gx = f.gx; a.ty0 = f.ty0; a.ty1 = f.ty1;
+    a.ranges = img.ranges; a.point_list = b.point_list; a.means2D = g.means2D; a.conic_opacity = g.conic_opacity;
+    a.cov3D_inv = g.cov3D_inv; a.features = f.colors_precomp ? f.colors_precomp : g.rgb; // reference rasterizer_impl.cu:367,473
+    a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.bg = f.background;
+    a.final_T = img.final_T; a.n_contrib = img.n_contrib;
+    return a;
+}
+
+// implemented in stp_render_hier_fwd.hip / stp_render_hier_bwd.hip / stp_render_full.hip
+hipError_t launch_hier_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
+hipError_t launch_hier_bwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
+hipError_t launch_full_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st);
+
+template <bool BACKWARD> static hipError_t launch_kbuffer(const FrameParams& f, const RenderArgs& a, hipStream_t st)
+{
+    const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(BLOCK);
+    const int w = f.s.queue_per_pixel; // reference forward.cu:409-425 / backward.cu:712-731
+#define STP_KB(WIN) hipLaunchKernelGGL((render_kbuffer_kernel<WIN, BACKWARD>), grid, block, 0, st, a)
+    if (w <= 1) STP_KB(1);
+    else if (w <= 2) STP_KB(2);
+    else if (w <= 4) STP_KB(4);
+    else if (w <= 8) STP_KB(8);
+    else if (w <= 12) STP_KB(12);
+    else if (w <= 16) STP_KB(16);
+    else if (w <= 20) STP_KB(20);
+    else STP_KB(24);
+#undef STP_KB
+    return hipGetLastError();
+}
+
+hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
+                                 float* out_color, hipStream_t st, std::string* err)
+{
+    RenderArgs a = make_args(f, g, b, img);
+    a.out_color = out_color;
+    const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(BLOCK);
+    if (grid.x == 0) return hipSuccess;
+    switch (f.s.sort_mode) {
+    case MODE_GLOBAL:
+        hipLaunchKernelGGL(render_global_fwd_kernel, grid, block, 0, st, a);
+        return hipGetLastError();
+    case MODE_KBUFFER: return launch_kbuffer<false>(f, a, st);
+    case MODE_FULL: return launch_full_fwd(f, a, st);
+    case MODE_HIER: return launch_hier_fwd(f, a, st, err);
+    default: if (err) *err = "invalid sort mode"; return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
+                                  const BackwardParams& bw, hipStream_t st, std::string* err)
+{
+    RenderArgs a = make_args(f, g, b, img);
+    a.pixel_colors = bw.pixel_colors; a.dL_dpix = bw.dL_dpix; a.dL_dmean2D = bw.dL_dmean2D; a.dL_dconic = bw.dL_dconic;
+    a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
+    const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(BLOCK);
+    if (grid.x == 0) return hipSuccess;
+    switch (f.s.sort_mode) {
+    case MODE_GLOBAL:
+        hipLaunchKernelGGL(render_global_bwd_kernel, grid, block, 0, st, a);
+        return hipGetLastError();
+    case MODE_KBUFFER: return launch_kbuffer<true>(f, a, st);
+    case MODE_HIER: return launch_hier_bwd(f, a, st, err);
+    default: if (err) *err = "Backward not supported for full per-pixel sort"; return hipErrorInvalidValue;
+    }
+}
+
+} // namespace stp

@@ -1,0 +1,283 @@
+"""`diff_gaussian_rasterization._C` -- host binding of libstp_raster.so.
+
+Mirrors the reference's pybind module of the same name (reference ext.cpp:15-19,
+rasterize_points.cu:43-253): the three functions below take and return exactly the tensors the
+reference's do, in the same order.  PyTorch is used for device memory and the current HIP stream only;
+all compute is in the hand-written HIP library reached through its C ABI (include/stp_raster.h) with
+ctypes -- no torch C++ extension, hence no hipify pass over our sources.
+
+There is NO fallback: if the library is missing or the tensors are not on a GPU, these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Tuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_NAME = "libstp_raster.so"
+_lib = None
+
+
+class StpSettings(ctypes.Structure):
+    """POD mirror of StpSettings (include/stp_raster.h) == reference SplattingSettings (rasterizer.h:129-135)."""
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "sort_mode", "sort_order", "queue_tile_4x4", "queue_tile_2x2", "queue_per_pixel",
+        "rect_bounding", "tight_opacity_bounding", "tile_based_culling", "hierarchical_4x4_culling",
+        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1")]
+
+
+_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+def library_path() -> str:
+    return os.environ.get("STP_RASTER_LIB", os.path.join(_HERE, _LIB_NAME))
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `make -C stopthepop-rasterization_amd/csrc` "
+            f"(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    L = ctypes.CDLL(path)
+    vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+    L.stp_forward.restype = ci
+    L.stp_forward.argtypes = [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci,
+                              ctypes.POINTER(StpSettings), vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, cf, cf, ci,
+                              vp, vp, ci, vp]
+    L.stp_backward.restype = ci
+    L.stp_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, ctypes.POINTER(StpSettings), vp, vp, vp, vp, vp, cf, vp, vp,
+                               vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp] + [vp] * 9 + [ci, vp]
+    L.stp_mark_visible.restype = ci
+    L.stp_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    L.stp_last_error.restype = ctypes.c_char_p
+    L.stp_abi_version.restype = ci
+    for name in ("stp_geometry_buffer_size", "stp_binning_buffer_size", "stp_image_buffer_size"):
+        getattr(L, name).restype = ctypes.c_size_t
+    L.stp_geometry_buffer_size.argtypes = [ci, ctypes.POINTER(StpSettings)]
+    L.stp_binning_buffer_size.argtypes = [ci]
+    L.stp_image_buffer_size.argtypes = [ci, ci]
+    szp = ctypes.POINTER(ctypes.c_size_t)
+    L.stp_geometry_layout.argtypes = [ci, ctypes.POINTER(StpSettings), ctypes.c_char_p, szp, szp]
+    L.stp_binning_layout.argtypes = [ci, ctypes.c_char_p, szp, szp]
+    L.stp_image_layout.argtypes = [ci, ci, ctypes.c_char_p, szp, szp]
+    L.stp_timing_enable.argtypes = [ci]
+    L.stp_timing_enable.restype = None
+    L.stp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float)]
+    L.stp_timing_read.restype = ci
+    if L.stp_abi_version() != 1:
+        raise ImportError("libstp_raster.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def settings_from_dict(d: dict, tile_rows=None) -> StpSettings:
+    """dict -> POD.  All keys are mandatory, as in the reference's json parser (rasterizer.h:160-182,
+    every field read with .at()); a missing key raises KeyError where the reference raised json::out_of_range."""
+    ss, cs = d["sort_settings"], d["culling_settings"]
+    q = ss["queue_sizes"]
+    s = StpSettings()
+    s.sort_mode = int(ss["sort_mode"])
+    s.sort_order = int(ss["sort_order"])
+    s.queue_tile_4x4 = int(q["tile_4x4"])
+    s.queue_tile_2x2 = int(q["tile_2x2"])
+    s.queue_per_pixel = int(q["per_pixel"])
+    s.rect_bounding = int(bool(cs["rect_bounding"]))
+    s.tight_opacity_bounding = int(bool(cs["tight_opacity_bounding"]))
+    s.tile_based_culling = int(bool(cs["tile_based_culling"]))
+    s.hierarchical_4x4_culling = int(bool(cs["hierarchical_4x4_culling"]))
+    s.load_balancing = int(bool(d["load_balancing"]))
+    s.proper_ewa_scaling = int(bool(d["proper_ewa_scaling"]))
+    tr = tile_rows if tile_rows is not None else d.get("_tile_rows")
+    if tr is not None:
+        s.tile_y0, s.tile_y1 = int(tr[0]), int(tr[1])
+    return s
+
+
+def _raise_last(rc: int):
+    msg = _load().stp_last_error()
+    raise RuntimeError((msg.decode() if msg else "") or f"libstp_raster error {rc}")
+
+
+def _ptr(t: torch.Tensor):
+    """Device pointer of a contiguous fp32/int32 tensor; empty tensor -> NULL (reference convention:
+    `torch.Tensor([])` marks an absent optional input and its data_ptr is null)."""
+    if t is None or t.numel() == 0:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _prep(t: torch.Tensor, device) -> torch.Tensor:
+    if t is None or t.numel() == 0:
+        return t
+    if t.device != device:
+        raise RuntimeError(f"expected all tensors on {device}, got one on {t.device}")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
+    return t.contiguous()
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _Resizer:
+    """The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request."""
+
+    def __init__(self, device):
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.cb = _ALLOC_FN(self._alloc)
+
+    def _alloc(self, _user, nbytes):
+        try:
+            self.tensor.resize_(int(nbytes))
+            return self.tensor.data_ptr() if nbytes else 0
+        except Exception:  # surfaces as STP_ERR_ALLOC on the C side
+            return 0
+
+
+def _require_gpu(means3D: torch.Tensor):
+    if not means3D.is_cuda:
+        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a GPU device; "
+                           "there is no CPU path in the product")
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, inv_viewprojmatrix, tan_fovx, tan_fovy, image_height, image_width,
+                        sh, degree, campos, prefiltered, settings_dict, render_depth, debug
+                        ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """== RasterizeGaussiansCUDA (reference rasterize_points.cu:43-138).
+    Returns (num_rendered, out_color (3,H,W), radii (P,) int32, geomBuffer, binningBuffer, imgBuffer)."""
+    L = _load()
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D)
+    if render_depth:
+        raise NotImplementedError("render_depth (debug depth visualisation) is outside the accelerated hot path")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+    rendered = 0
+    if P != 0:
+        M = int(sh.size(1)) if sh.numel() != 0 else 0
+        s = settings_from_dict(settings_dict)
+        t = [_prep(x, dev) for x in (background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp,
+                                     viewmatrix, projmatrix, inv_viewprojmatrix, campos)]
+        bg_, m3_, sh_, col_, op_, sc_, ro_, c3_, vm_, pm_, inv_, cam_ = t
+        with torch.cuda.device(dev):
+            rc = L.stp_forward(geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_), W, H,
+                               ctypes.byref(s), _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_),
+                               ctypes.c_float(scale_modifier), _ptr(ro_), _ptr(c3_), _ptr(vm_), _ptr(pm_), _ptr(inv_),
+                               _ptr(cam_), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)),
+                               _ptr(out_color), _ptr(radii), int(bool(debug)), _stream_ptr(dev))
+        if rc < 0:
+            _raise_last(rc)
+        rendered = rc
+    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, scales, rotations, scale_modifier,
+                                 cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, tan_fovx, tan_fovy,
+                                 pixel_colors, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
+                                 imageBuffer, settings_dict, debug):
+    """== RasterizeGaussiansBackwardCUDA (reference rasterize_points.cu:140-232).
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    L = _load()
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if sh.numel() != 0 else 0
+    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
+    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
+    dL_dconic, dL_dopacity, dL_dcov3D = z(P, 2, 2), z(P, 1), z(P, 6)
+    dL_dsh, dL_dscales, dL_drotations = z(P, M, 3), z(P, 3), z(P, 4)
+    s = settings_from_dict(settings_dict)
+    if P != 0:
+        t = [_prep(x, dev) for x in (background, means3D, sh, colors, opacities, scales, rotations, cov3D_precomp,
+                                     viewmatrix, projmatrix, inv_viewprojmatrix, campos, pixel_colors, dL_dout_color)]
+        bg_, m3_, sh_, col_, op_, sc_, ro_, c3_, vm_, pm_, inv_, cam_, pix_, dl_ = t
+        radii_ = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = L.stp_backward(P, int(degree), M, int(R), _ptr(bg_), W, H, ctypes.byref(s), _ptr(m3_), _ptr(sh_),
+                                _ptr(op_), _ptr(col_), _ptr(sc_), ctypes.c_float(scale_modifier), _ptr(ro_), _ptr(c3_),
+                                _ptr(vm_), _ptr(pm_), _ptr(inv_), _ptr(cam_), ctypes.c_float(tan_fovx),
+                                ctypes.c_float(tan_fovy), _ptr(pix_), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer),
+                                _ptr(imageBuffer), _ptr(dl_), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
+                                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
+                                _ptr(dL_drotations), int(bool(debug)), _stream_ptr(dev))
+        if rc < 0:
+            _raise_last(rc)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+
+
+def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
+    """== markVisible (reference rasterize_points.cu:234-253)."""
+    L = _load()
+    _require_gpu(means3D)
+    dev = means3D.device
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m3_, vm_, pm_ = (_prep(x, dev) for x in (means3D, viewmatrix, projmatrix))
+        with torch.cuda.device(dev):
+            rc = L.stp_mark_visible(P, _ptr(m3_), _ptr(vm_), _ptr(pm_), ctypes.c_void_p(present.data_ptr()), _stream_ptr(dev))
+        if rc < 0:
+            _raise_last(rc)
+    return present
+
+
+# ---- introspection helpers (tests / bench; not part of the reference surface) -----------------------
+_GEOM_TYPES = {"depths": torch.float32, "clamped": torch.uint8, "radii": torch.int32, "rects2D": torch.float32,
+               "means2D": torch.float32, "cov3D": torch.float32, "cov3D_inv": torch.float32,
+               "conic_opacity": torch.float32, "rgb": torch.float32, "tiles_touched": torch.int32,
+               "point_offsets": torch.int32}
+_BIN_TYPES = {"point_list": torch.int32, "point_list_unsorted": torch.int32, "keys": torch.int64, "keys_unsorted": torch.int64}
+_IMG_TYPES = {"final_T": torch.float32, "n_contrib": torch.int32, "ranges": torch.int32}
+
+
+def _view(buf: torch.Tensor, off: int, count: int, dtype) -> torch.Tensor:
+    nbytes = count * torch.empty((), dtype=dtype).element_size()
+    return buf[off:off + nbytes].view(dtype)
+
+
+def geometry_array(geomBuffer, P, settings_dict, name):
+    s = settings_from_dict(settings_dict)
+    off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+    if _load().stp_geometry_layout(int(P), ctypes.byref(s), name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
+        raise KeyError(name)
+    return _view(geomBuffer, off.value, cnt.value, _GEOM_TYPES[name])
+
+
+def binning_array(binningBuffer, R, name):
+    off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+    if _load().stp_binning_layout(int(R), name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
+        raise KeyError(name)
+    return _view(binningBuffer, off.value, cnt.value, _BIN_TYPES[name])
+
+
+def image_array(imgBuffer, W, H, name):
+    off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+    if _load().stp_image_layout(int(W), int(H), name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
+        raise KeyError(name)
+    return _view(imgBuffer, off.value, cnt.value, _IMG_TYPES[name])
+
+
+def timing_enable(flag: bool) -> None:
+    _load().stp_timing_enable(int(bool(flag)))
+
+
+def timing_read():
+    """Milliseconds of the last call's stages: Preprocess, Duplicate, Sort, Render, BwdRender, BwdPreprocess."""
+    arr = (ctypes.c_float * 6)()
+    _load().stp_timing_read(arr)
+    names = ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess")
+    return {n: float(v) for n, v in zip(names, arr)}

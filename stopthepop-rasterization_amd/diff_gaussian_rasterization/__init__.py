@@ -1,0 +1,227 @@
+"""diff_gaussian_rasterization -- MI355X-native drop-in for the StopThePop rasterizer's Python API.
+
+Public surface (names, argument order, field order, defaults, error texts) follows the reference
+package of the same name (reference diff_gaussian_rasterization/__init__.py):
+  rasterize_gaussians            :32-53      _RasterizeGaussians (autograd.Function)  :55-172
+  SortMode / GlobalSortOrder     :175-191    SortQueueSizes / SortSettings / CullingSettings / ExtendedSettings :193-246
+  GaussianRasterizationSettings  :248-263    GaussianRasterizer (nn.Module)           :265-314
+A trainer written against the reference imports this package unchanged.  The compute behind `_C` is the
+hand-written HIP library (csrc/), reached through its C ABI; see _C.py.
+
+Differences that do not change behaviour: the settings dataclasses use default_factory (the
+reference's shared mutable defaults are rejected by Python >= 3.11); `dacite` is optional (only
+ExtendedSettings.from_dict used it).
+"""
+from __future__ import annotations
+
+import json
+from dataclasses import asdict, dataclass, field, fields
+from enum import IntEnum
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+__all__ = ["rasterize_gaussians", "SortMode", "GlobalSortOrder", "SortQueueSizes", "SortSettings", "CullingSettings",
+           "ExtendedSettings", "GaussianRasterizationSettings", "GaussianRasterizer"]
+
+
+def enum_dict_factory(data):
+    """asdict() factory that stores IntEnum members as plain ints (the C side reads ints)."""
+    return {k: (v.value if isinstance(v, IntEnum) else v) for k, v in data}
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    return tuple(item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        # positional layout of _C.rasterize_gaussians (22 arguments)
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.settings.to_dict(), rs.render_depth,
+                rs.debug)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)  # snapshot before anything can corrupt them
+            try:
+                num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_fw.dump")
+                print("\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
+                raise ex
+        else:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
+                              geomBuffer, binningBuffer, imgBuffer)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        num_rendered = ctx.num_rendered
+        rs = ctx.raster_settings
+        (colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color, geomBuffer,
+         binningBuffer, imgBuffer) = ctx.saved_tensors
+        # positional layout of _C.rasterize_gaussians_backward (25 arguments)
+        args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
+                rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.settings.to_dict(),
+                rs.debug)
+        if rs.debug:
+            cpu_args = cpu_deep_copy_tuple(args)
+            try:
+                out = _C.rasterize_gaussians_backward(*args)
+            except Exception as ex:
+                torch.save(cpu_args, "snapshot_bw.dump")
+                print("\nAn error occured in backward. Writing snapshot_bw.dump for debugging.\n")
+                raise ex
+        else:
+            out = _C.rasterize_gaussians_backward(*args)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = out
+        # one gradient per forward input, in forward's order
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+class SortMode(IntEnum):
+    GLOBAL = 0
+    PPX_FULL = 1
+    PPX_KBUFFER = 2
+    HIER = 3
+
+    def __str__(self):
+        return self.name
+
+
+class GlobalSortOrder(IntEnum):
+    Z_DEPTH = 0
+    DISTANCE = 1
+    PTD_CENTER = 2
+    PTD_MAX = 3
+
+    def __str__(self):
+        return self.name
+
+
+class _Settable:
+    """set_value(key, value): set an own field, otherwise hand the key down (reference :199-246)."""
+    _children = ()
+
+    def set_value(self, key, value):
+        if key in {f.name for f in fields(self)}:
+            setattr(self, key, value)
+        else:
+            for child in self._children:
+                getattr(self, child).set_value(key, value)
+
+
+@dataclass
+class SortQueueSizes(_Settable):
+    tile_4x4: int = 64
+    tile_2x2: int = 8
+    per_pixel: int = 4
+
+
+@dataclass
+class SortSettings(_Settable):
+    queue_sizes: SortQueueSizes = field(default_factory=SortQueueSizes)
+    sort_mode: SortMode = SortMode.GLOBAL
+    sort_order: GlobalSortOrder = GlobalSortOrder.Z_DEPTH
+    _children = ("queue_sizes",)
+
+
+@dataclass
+class CullingSettings(_Settable):
+    rect_bounding: bool = False
+    tight_opacity_bounding: bool = False
+    tile_based_culling: bool = False
+    hierarchical_4x4_culling: bool = False
+
+
+@dataclass
+class ExtendedSettings(_Settable):
+    sort_settings: SortSettings = field(default_factory=SortSettings)
+    culling_settings: CullingSettings = field(default_factory=CullingSettings)
+    load_balancing: bool = False
+    proper_ewa_scaling: bool = False
+    _children = ("culling_settings", "sort_settings")
+
+    def to_dict(self):
+        return asdict(self, dict_factory=enum_dict_factory)
+
+    def to_json(self):
+        return json.dumps(self.to_dict())
+
+    @staticmethod
+    def from_dict(dict):
+        try:
+            import dacite
+            return dacite.from_dict(data_class=ExtendedSettings, data=dict, config=dacite.Config(cast=[IntEnum]))
+        except ImportError:
+            ss, cs = dict["sort_settings"], dict["culling_settings"]
+            return ExtendedSettings(
+                sort_settings=SortSettings(queue_sizes=SortQueueSizes(**ss["queue_sizes"]), sort_mode=SortMode(ss["sort_mode"]),
+                                           sort_order=GlobalSortOrder(ss["sort_order"])),
+                culling_settings=CullingSettings(**cs), load_balancing=dict["load_balancing"],
+                proper_ewa_scaling=dict["proper_ewa_scaling"])
+
+    @staticmethod
+    def from_json(json_filename):
+        return ExtendedSettings.from_dict(json.load(open(json_filename)))
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    inv_viewprojmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    settings: ExtendedSettings
+    render_depth: bool
+    debug: bool
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        """Boolean mask of the points that pass the camera's near-plane test."""
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = lambda t: torch.Tensor([]) if t is None else t  # absent optional input == empty CPU tensor
+        return rasterize_gaussians(means3D, means2D, empty(shs), empty(colors_precomp), opacities, empty(scales),
+                                   empty(rotations), empty(cov3D_precomp), rs)

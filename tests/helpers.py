@@ -1,0 +1,96 @@
+"""Shared helpers of the parity tests: settings dicts, running the product (GPU) and the oracle (CPU)
+on the same synthetic scene, and comparison metrics."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def settings_dict(mode=0, order=0, per_pixel=4, tile_2x2=8, rect=False, tight=False, tbc=False, h44=False,
+                  lb=False, ewa=False):
+    """The reference's ExtendedSettings.to_dict() layout."""
+    return {"sort_settings": {"queue_sizes": {"tile_4x4": 64, "tile_2x2": tile_2x2, "per_pixel": per_pixel},
+                              "sort_mode": mode, "sort_order": order},
+            "culling_settings": {"rect_bounding": rect, "tight_opacity_bounding": tight, "tile_based_culling": tbc,
+                                 "hierarchical_4x4_culling": h44},
+            "load_balancing": lb, "proper_ewa_scaling": ewa}
+
+
+FULL_STP = dict(mode=3, order=3, rect=True, tight=True, tbc=True, h44=True, lb=True)  # "full StopThePop" (C2-full)
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 200.0 if mse == 0 else 10.0 * np.log10(1.0 / mse)
+
+
+def max_abs(a, b):
+    return float(np.max(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)))) if np.size(a) else 0.0
+
+
+def ext_settings(d):
+    """dict -> diff_gaussian_rasterization.ExtendedSettings"""
+    import diff_gaussian_rasterization as dgr
+    return dgr.ExtendedSettings.from_dict(d)
+
+
+class GpuRun:
+    """Runs one scene through the product's public API on cuda:0 and keeps what the tests inspect."""
+
+    def __init__(self, scene, sdict, backward=True, device="cuda:0", tile_rows=None, debug=False):
+        import torch
+        import diff_gaussian_rasterization as dgr
+        from diff_gaussian_rasterization import _C
+        self.scene, self.sdict = scene, sdict
+        dev = torch.device(device)
+        t = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev).requires_grad_(rg)
+        self.means3D, self.opac = t(scene.means3D, True), t(scene.opacities, True)
+        self.scales, self.rots = t(scene.scales, True), t(scene.rotations, True)
+        self.shs, self.colors = t(scene.shs, True), t(scene.colors_precomp, True)
+        self.means2D = torch.zeros_like(self.means3D, requires_grad=True)
+        es = ext_settings(sdict)
+        if tile_rows is not None:
+            # tile-row window rides along in the dict through a private key (see _C.settings_from_dict)
+            base = es.to_dict
+            es.to_dict = lambda: {**base(), "_tile_rows": tuple(tile_rows)}
+        rs = dgr.GaussianRasterizationSettings(
+            image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
+            scale_modifier=scene.scale_modifier, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix),
+            inv_viewprojmatrix=t(scene.inv_viewprojmatrix), sh_degree=scene.sh_degree, campos=t(scene.campos),
+            prefiltered=False, settings=es, render_depth=False, debug=debug)
+        self.rs = rs
+        rast = dgr.GaussianRasterizer(rs)
+        color, radii = rast(self.means3D, self.means2D, self.opac, shs=self.shs, colors_precomp=self.colors,
+                            scales=self.scales, rotations=self.rots)
+        self.color_t = color
+        self.color = color.detach().cpu().numpy()
+        self.radii = radii.cpu().numpy()
+        fn = color.grad_fn
+        self.num_rendered = fn.num_rendered
+        saved = fn.saved_tensors
+        self.geom, self.binning, self.img = saved[9], saved[10], saved[11]
+        self._C = _C
+        self.grads = None
+        if backward:
+            w = torch.tensor(scene.dL_dout, device=dev)
+            (color * w).sum().backward()
+            g = lambda x: None if x is None or x.grad is None else x.grad.detach().cpu().numpy()
+            self.grads = dict(dL_dmeans3D=g(self.means3D), dL_dmeans2D=g(self.means2D), dL_dopacity=g(self.opac),
+                              dL_dscales=g(self.scales), dL_drotations=g(self.rots), dL_dsh=g(self.shs),
+                              dL_dcolors=g(self.colors))
+
+    def geom_array(self, name):
+        return self._C.geometry_array(self.geom, self.scene.P, self.sdict, name).cpu().numpy()
+
+    def binning_array(self, name):
+        a = self._C.binning_array(self.binning, self.num_rendered, name).cpu().numpy()
+        return a.view(np.uint64) if a.dtype == np.int64 else a.view(np.uint32)
+
+    def image_array(self, name):
+        return self._C.image_array(self.img, self.scene.W, self.scene.H, name).cpu().numpy()
+
+
+def oracle_run(scene, sdict, backward=True, tile_rows=None):
+    from oracle import oracle as orc
+    f = orc.forward_scene(scene, sdict, tile_rows=tile_rows)
+    g = f.backward(scene.dL_dout) if backward else None
+    return f, g
