@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X rasterizer hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one forward + backward pass of the hot path over one synthetic frame of BASELINE.json's
+headline configuration (C2: 1M Gaussians, 1920x1080, hierarchical sort; `--variant full` = PTD_MAX order +
+rect/tight/tile-based/4x4 culling + load balancing, `--variant min` = plain Z order, no culling), inputs
+resident in HBM, through the public drop-in API (GaussianRasterizer -> autograd -> _C -> C ABI).
+Rank 0 prints ONE JSON line (contract in the task statement / DESIGN.md section "Measurement").
+
+N > 1 (default `--shard tilerows`): the frame is partitioned by screen-tile row; every rank renders its
+rows, the image strips are gathered to rank 0 over RCCL, the per-Gaussian partial gradients are
+all-reduced (strong scaling: the work per step is one frame regardless of N).  `--shard frames` runs N
+independent frames instead (weak scaling).
+
+The `cpu_baseline` leg (rank 0, N == 1 only) times the CPU oracle on a bounded sample of the same frame:
+it is a reported, non-target baseline.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "stopthepop-rasterization_amd"))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); measured copy ceiling ~6290 GB/s
+
+
+def settings_for(variant: str, workload: str):
+    import diff_gaussian_rasterization as dgr
+    es = dgr.ExtendedSettings()
+    if workload == "C3":
+        es.sort_settings.sort_mode = dgr.SortMode.PPX_KBUFFER
+        es.sort_settings.queue_sizes.per_pixel = 16
+        return es
+    if workload == "C1":
+        return es
+    es.sort_settings.sort_mode = dgr.SortMode.HIER
+    if variant == "full":
+        es.sort_settings.sort_order = dgr.GlobalSortOrder.PTD_MAX
+        es.culling_settings.rect_bounding = True
+        es.culling_settings.tight_opacity_bounding = True
+        es.culling_settings.tile_based_culling = True
+        es.culling_settings.hierarchical_4x4_culling = True
+        es.load_balancing = True
+    return es
+
+
+def algorithmic_bytes(P, P_v, R, N, T, M, S, mode_hier, K, E, sh):
+    """Compulsory HBM traffic per stage, bytes."""
+    b = {}
+    b["preprocess"] = P * (44 + 8) + P_v * (12 * M * sh + 60 + 48 * S + 15 * sh)
+    b["scan"] = 8 * P
+    b["duplicate"] = 8 * P + P_v * (20 + 16 * E + 48 * K) + 12 * R
+    b["sort"] = 24 * R
+    b["ranges"] = 8 * R + 16 * T
+    b["render_fwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (0 if mode_hier else 4))
+    b["zero_fill"] = P * (108 + 12 * M)
+    b["render_bwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (12 if S else 4)) + 88 * P_v
+    b["bwd_preprocess"] = 4 * P + P_v * (52 + 36) + 4 * P + P_v * (36 + sh * (12 * M + 15) + 52) + P_v * (12 + sh * 12 * M + 28)
+    return b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
+    ap.add_argument("--variant", default="full", choices=["full", "min"])
+    ap.add_argument("--shard", default="tilerows", choices=["tilerows", "frames"])
+    ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalidates the headline number)")
+    ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)
+        dist = dist_mod
+
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C, scenes, tile_shard
+
+    fwd_only = args.fwd_only or args.workload == "C4"
+    scene = scenes.config(args.workload, scale=args.scale)
+    es = settings_for(args.variant, args.workload)
+    sdict = es.to_dict()
+    t = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev).requires_grad_(rg and not fwd_only)
+    means3D, opac = t(scene.means3D, True), t(scene.opacities, True)
+    scales, rots, shs = t(scene.scales, True), t(scene.rotations, True), t(scene.shs, True)
+    means2D = torch.zeros_like(means3D, requires_grad=not fwd_only)
+    w_img = t(scene.dL_dout)
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
+        scale_modifier=1.0, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix),
+        inv_viewprojmatrix=t(scene.inv_viewprojmatrix), sh_degree=scene.sh_degree, campos=t(scene.campos),
+        prefiltered=False, settings=es, render_depth=False, debug=False)
+
+    gy = (scene.H + 15) // 16
+    sharded = world > 1 and args.shard == "tilerows"
+    if sharded:
+        raster = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
+    else:
+        raster = dgr.GaussianRasterizer(rs)
+    leaves = [means3D, means2D, opac, scales, rots, shs]
+    state = {}
+
+    def step():
+        for x in leaves:
+            if x is not None and x.grad is not None:
+                x.grad = None
+        color, radii = raster(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+        state["color"], state["radii"] = color, radii
+        if not fwd_only:
+            (color * w_img).sum().backward()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    _C.timing_enable(True)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if rank == 0:  # event reads are post-hoc (they wait on already recorded events of this step)
+            pass
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-stage device times (hipEvents on the launch stream) of a few extra, untimed steps
+    n_probe = 5
+    for _ in range(n_probe):
+        step()
+        torch.cuda.synchronize(dev)
+        for k, v in _C.timing_read().items():
+            if v >= 0:
+                stage_acc.setdefault(k, []).append(v)
+    _C.timing_enable(False)
+    stage_ms = {k: float(np.median(v)) for k, v in stage_acc.items()}
+
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    frames_per_step = world if (world > 1 and not sharded) else 1
+    value = frames_per_step * args.steps / dt
+    ms_per_step = 1000.0 * dt / args.steps
+
+    if rank == 0:
+        # measured sizes for the byte model
+        radii = state["radii"]
+        P = scene.P
+        P_v = int((radii > 0).sum().item())
+        fn = state["color"].grad_fn
+        R = int(getattr(fn, "num_rendered", 0)) if fn is not None else 0
+        N = scene.W * scene.H
+        T = ((scene.W + 15) // 16) * gy
+        mode = int(sdict["sort_settings"]["sort_mode"])
+        order = int(sdict["sort_settings"]["sort_order"])
+        S = 1 if (mode != 0 or order >= 2) else 0
+        Kf = 1 if order >= 2 else 0
+        E = 1 if (sdict["culling_settings"]["tile_based_culling"] or order == 3) else 0
+        bts = algorithmic_bytes(P, P_v, R, N, T, 16, S, mode == 3, Kf, E, 1)
+        dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
+        dom_bytes = bts["render_bwd"] if dom == "BwdRender" else bts["render_fwd"]
+        dom_ms = stage_ms.get(dom, float("nan"))
+        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
+        fwd_bytes = sum(bts[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"))
+        bwd_bytes = sum(bts[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess"))
+        out = {
+            "metric": "fwd+bwd frames/sec at 1920×1080, 1M Gaussians; PSNR vs reference",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}-{args.variant}: {P} Gaussians, {scene.W}x{scene.H}, SH degree 3, "
+                                   f"sort_mode={mode} sort_order={order} culling={sdict['culling_settings']} "
+                                   f"{'fwd' if fwd_only else 'fwd+bwd'}",
+                       "P": P, "P_visible": P_v, "num_rendered": R, "tiles": T,
+                       "parallelism": (f"tilerows{world}" if sharded else f"frames{world}") if world > 1 else "single",
+                       "scale": args.scale},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "algorithmic_bytes": {"forward": int(fwd_bytes), "backward": int(bwd_bytes)},
+            "roofline": {"bound": "hbm", "kernel": "render_hier_kernel" + ("<backward>" if dom == "BwdRender" else "<forward>"),
+                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
+                         "whole_step_frac": round(((fwd_bytes + (0 if fwd_only else bwd_bytes)) / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, sdict, gy, fwd_only, args.cpu_rows)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(scene, sdict, gy, fwd_only, rows):
+    """Oracle (our CPU restatement, OpenMP over all host cores) on a bounded sample of the same frame:
+    a centred window of tile rows, time extrapolated linearly to the full frame."""
+    from oracle import oracle as orc
+    cores = orc.num_threads()
+    if rows <= 0:
+        rows = max(1, min(gy, int(round(gy * min(1.0, 2.0e5 / max(scene.P, 1))))))  # ~20 s of CPU work at C2
+    y0 = max(0, (gy - rows) // 2)
+    t0 = time.perf_counter()
+    f = orc.forward_scene(scene, sdict, tile_rows=(y0, y0 + rows))
+    if not fwd_only:
+        f.backward(scene.dL_dout)
+    dt = time.perf_counter() - t0
+    f.free()
+    est_frame_s = dt * gy / rows
+    return {"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"tile rows {y0}..{y0 + rows - 1} of {gy} of the same frame ({'fwd' if fwd_only else 'fwd+bwd'}), "
+                      f"{dt:.1f} s measured, extrapolated x{gy / rows:.2f}"}
+
+
+if __name__ == "__main__":
+    main()

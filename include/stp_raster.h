@@ -104,6 +104,25 @@ int stp_backward(int P, int D, int M, int R,
                  float* dL_dsh /* P x M x 3 */, float* dL_dscale /* P x 3 */, float* dL_drot /* P x 4 */,
                  int debug, void* stream);
 
+/* Extension (not in the reference): the two halves of the backward separately, for tile-row sharding.
+   phases bit 0 = BACKWARD::render (rasterizer_impl.cu:474-495): accumulates the per-Gaussian partial
+   sums dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor of THIS rank's tile rows;
+   phases bit 1 = BACKWARD::preprocess (rasterizer_impl.cu:501-525): consumes those four arrays (after the
+   caller has summed them across ranks) and writes the remaining gradients.  phases = 3 == stp_backward. */
+int stp_backward_phases(int phases, int P, int D, int M, int R,
+                        const float* background, int width, int height,
+                        const StpSettings* settings,
+                        const float* means3D, const float* shs, const float* opacities, const float* colors_precomp,
+                        const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                        const float* viewmatrix, const float* projmatrix, const float* inv_viewprojmatrix,
+                        const float* cam_pos, float tan_fovx, float tan_fovy,
+                        const float* pixel_colors, const int* radii,
+                        char* geom_buffer, char* binning_buffer, char* image_buffer,
+                        const float* dL_dpix,
+                        float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                        float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+                        int debug, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:188-193, rasterizer_impl.cu:161-173).
    `present` is P bytes (bool). */
 int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -385,14 +385,18 @@ void preprocess(OrcFrame& f, const float* means3D, const float* shs, const float
 
         const float ext_x = std::min(s.rect_bounding ? (extent * sqrtf(c2x)) : radius, radius);
         const float ext_y = std::min(s.rect_bounding ? (extent * sqrtf(c2z)) : radius, radius);
+        // visibility is decided on the full frame (ref: forward.cu:177-196); tiles_touched counts the
+        // tiles inside the tile-row window only (our sharding extension; window == frame by default)
+        int fx0, fy0, fx1, fy1;
+        get_rect(mean2D, {ext_x, ext_y}, f.gx, f.gy, 0, f.gy, fx0, fy0, fx1, fy1);
+        if ((fx1 - fx0) * (fy1 - fy0) == 0) continue;
         int x0, y0, x1, y1;
         get_rect(mean2D, {ext_x, ext_y}, f.gx, f.gy, ty0, ty1, x0, y0, x1, y1);
-        const int rect_tiles = (x1 - x0) * (y1 - y0);
-        if (rect_tiles == 0) continue;
-
-        int tile_count = rect_tiles;
-        if (s.tile_based_culling) tile_count = tbc_tile_count(co, mean2D, thr, x0, y0, x1, y1);
-        if (tile_count == 0) continue;
+        int tile_count = (x1 - x0) * (y1 - y0);
+        if (s.tile_based_culling) {
+            if (tbc_tile_count(co, mean2D, thr, fx0, fy0, fx1, fy1) == 0) continue;
+            tile_count = tbc_tile_count(co, mean2D, thr, x0, y0, x1, y1);
+        }
 
         if (!colors_precomp) color_from_sh(idx, f.D, f.M, mean, cam, shs, f.clamped.data(), f.rgb.data());
 

@@ -319,7 +319,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     return R;
 }
 
-int stp_backward(int P, int D, int M, int R, const float* background, int width, int height, const StpSettings* settings,
+int stp_backward_phases(int phases, int P, int D, int M, int R, const float* background, int width, int height, const StpSettings* settings,
                  const float* means3D, const float* shs, const float* opacities, const float* colors_precomp, const float* scales,
                  float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* inv_viewprojmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
@@ -332,8 +332,9 @@ int stp_backward(int P, int D, int M, int R, const float* background, int width,
     if (P == 0) return 0; // reference rasterize_points.cu:191
     if (int rc = check_settings(*settings, true)) return rc;
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail(STP_ERR_INVALID_ARGUMENT, "null scratch buffer");
-    if (!dL_dpix || !pixel_colors || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)
-        return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
+    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor) return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
+    if ((phases & 1) && (!dL_dpix || !pixel_colors)) return fail(STP_ERR_INVALID_ARGUMENT, "null image gradient");
+    if ((phases & 2) && (!dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)) return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
 
     FrameParams f;
     fill_frame(f, P, D, M, background, width, height, *settings, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
@@ -349,20 +350,39 @@ int stp_backward(int P, int D, int M, int R, const float* background, int width,
     bw.dL_dopacity = dL_dopacity; bw.dL_dcolor = dL_dcolor; bw.dL_dmean3D = dL_dmean3D; bw.dL_dcov3D = dL_dcov3D; bw.dL_dsh = dL_dsh;
     bw.dL_dscale = dL_dscale; bw.dL_drot = dL_drot;
 
-    g_timer.reset_bwd();
-    g_timer.mark(5, st);
-    std::string err;
-    hipError_t e = launch_render_backward(f, g, b, img, bw, st, &err);
-    if (e != hipSuccess) {
-        if (!err.empty()) return fail(settings->sort_mode == MODE_FULL ? STP_ERR_NO_BACKWARD : STP_ERR_QUEUE_SIZE, err);
-        return fail_hip(e, "backward render launch");
+    if (phases & 1) {
+        g_timer.reset_bwd();
+        g_timer.mark(5, st);
+        std::string err;
+        hipError_t e = launch_render_backward(f, g, b, img, bw, st, &err);
+        if (e != hipSuccess) {
+            if (!err.empty()) return fail(settings->sort_mode == MODE_FULL ? STP_ERR_NO_BACKWARD : STP_ERR_QUEUE_SIZE, err);
+            return fail_hip(e, "backward render launch");
+        }
+        STP_DEBUG_SYNC("backward render");
+        g_timer.mark(6, st);
     }
-    STP_DEBUG_SYNC("backward render");
-    g_timer.mark(6, st);
-    STP_TRY(launch_preprocess_backward(f, g, radii, bw, st), "backward preprocess launch");
-    STP_DEBUG_SYNC("backward preprocess");
-    g_timer.mark(7, st);
+    if (phases & 2) {
+        if (!(phases & 1)) g_timer.mark(6, st);
+        STP_TRY(launch_preprocess_backward(f, g, radii, bw, st), "backward preprocess launch");
+        STP_DEBUG_SYNC("backward preprocess");
+        g_timer.mark(7, st);
+    }
     return 0;
+}
+
+int stp_backward(int P, int D, int M, int R, const float* background, int width, int height, const StpSettings* settings,
+                 const float* means3D, const float* shs, const float* opacities, const float* colors_precomp, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* inv_viewprojmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                 const float* pixel_colors, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
+                 const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
+{
+    return stp_backward_phases(3, P, D, M, R, background, width, height, settings, means3D, shs, opacities, colors_precomp, scales,
+                               scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, cam_pos, tan_fovx,
+                               tan_fovy, pixel_colors, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                               dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
 }
 
 int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present, void* stream)

@@ -82,8 +82,10 @@ __device__ __forceinline__ bool blend_forward(FwdPixel& p, const float* __restri
 
 // Gradient of one blended pair, front-to-back formulation: the colour behind the current entry is
 // reconstructed from the forward image, accum_rec = (final_colour - C_so_far) / T_after.
-// Nine fp32 atomics per pair (hardware global_atomic_add_f32; build with -munsafe-fp-atomics).
-__device__ __forceinline__ bool blend_backward(BwdPixel& b, const RenderArgs& a, int px, int py, int id, float G)
+// Produces the nine per-Gaussian terms g[0..2] = dL/dcolour, g[3..4] = dL/dmean2D (x,y),
+// g[5..7] = dL/dconic (xx, xy, yy), g[8] = dL/dopacity; the caller decides how they are accumulated.
+// Returns false (and leaves g untouched) when the pixel saturates.
+__device__ __forceinline__ bool blend_backward_terms(BwdPixel& b, const RenderArgs& a, int px, int py, int id, float G, float (&g)[9])
 {
     const float4 co = a.conic_opacity[id];
     const float alpha = fminf(0.99f, co.w * G);
@@ -99,7 +101,7 @@ __device__ __forceinline__ bool blend_backward(BwdPixel& b, const RenderArgs& a,
         b.C[ch] += c * alpha * b.T;
         const float accum_rec = (b.final_color[ch] - b.C[ch]) / test_T;
         dL_dalpha += (c - accum_rec) * b.dL_dpix[ch];
-        atomicAdd(&a.dL_dcolor[3 * (size_t)id + ch], dchannel_dcolor * b.dL_dpix[ch]);
+        g[ch] = dchannel_dcolor * b.dL_dpix[ch];
     }
     dL_dalpha *= b.T;
     dL_dalpha += (-b.T_final / (1.f - alpha)) * b.bg_dot;
@@ -107,13 +109,34 @@ __device__ __forceinline__ bool blend_backward(BwdPixel& b, const RenderArgs& a,
     const float gdx = G * dx, gdy = G * dy;
     const float dG_ddelx = -gdx * co.x - gdy * co.y;
     const float dG_ddely = -gdy * co.z - gdx * co.y;
-    atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 0], dL_dG * dG_ddelx * (0.5f * (float)a.W));
-    atomicAdd(&a.dL_dmean2D[3 * (size_t)id + 1], dL_dG * dG_ddely * (0.5f * (float)a.H));
-    atomicAdd(&a.dL_dconic[4 * (size_t)id + 0], -0.5f * gdx * dx * dL_dG);
-    atomicAdd(&a.dL_dconic[4 * (size_t)id + 1], -0.5f * gdx * dy * dL_dG);
-    atomicAdd(&a.dL_dconic[4 * (size_t)id + 3], -0.5f * gdy * dy * dL_dG);
-    atomicAdd(&a.dL_dopacity[id], G * dL_dalpha);
+    g[3] = dL_dG * dG_ddelx * (0.5f * (float)a.W);
+    g[4] = dL_dG * dG_ddely * (0.5f * (float)a.H);
+    g[5] = -0.5f * gdx * dx * dL_dG;
+    g[6] = -0.5f * gdx * dy * dL_dG;
+    g[7] = -0.5f * gdy * dy * dL_dG;
+    g[8] = G * dL_dalpha;
     b.T = test_T;
+    return true;
+}
+
+// destination of term k of Gaussian id in the reference's gradient tensors
+// (dL_dcolors P x 3, dL_dmeans2D P x 3 [z unused], dL_dconic P x 4 [.z unused], dL_dopacity P)
+__device__ __forceinline__ float* grad_slot(const RenderArgs& a, int id, int k)
+{
+    if (k < 3) return &a.dL_dcolor[3 * (size_t)id + k];
+    if (k < 5) return &a.dL_dmean2D[3 * (size_t)id + (k - 3)];
+    if (k < 8) return &a.dL_dconic[4 * (size_t)id + (k == 7 ? 3 : k - 5)];
+    return &a.dL_dopacity[id];
+}
+
+// Straightforward accumulation: nine hardware fp32 atomics (global_atomic_add_f32; build with
+// -munsafe-fp-atomics) per blended pair -- what the reference does (hierarchical_render.cuh:1131-1161).
+__device__ __forceinline__ bool blend_backward(BwdPixel& b, const RenderArgs& a, int px, int py, int id, float G)
+{
+    float g[9];
+    if (!blend_backward_terms(b, a, px, py, id, G, g)) return false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) atomicAdd(grad_slot(a, id, k), g[k]);
     return true;
 }
 

@@ -171,24 +171,30 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     const float ext_x = fminf(a.rect_bounding ? (extent * sqrtf(c2x)) : radius, radius);
     const float ext_y = fminf(a.rect_bounding ? (extent * sqrtf(c2z)) : radius, radius);
     const float2 rect_dims = make_float2(ext_x, ext_y);
-    int x0, y0, x1, y1;
-    get_rect(mean2D, rect_dims, a.gx, a.gy, a.ty0, a.ty1, x0, y0, x1, y1);
-    const int rect_tiles = (x1 - x0) * (y1 - y0);
-    if (rect_tiles == 0) return;
+    // Visibility (radii, colours, Sigma^-1 ...) is decided on the FULL frame, exactly as in the reference;
+    // tiles_touched counts only the tiles inside this rank's tile-row window [ty0, ty1).  Without
+    // sharding the window is the whole frame and the two coincide.
+    int fx0, fy0, fx1, fy1;
+    get_rect(mean2D, rect_dims, a.gx, a.gy, 0, a.gy, fx0, fy0, fx1, fy1);
+    if ((fx1 - fx0) * (fy1 - fy0) == 0) return;
+    const int x0 = fx0, x1 = fx1, y0 = min(max(fy0, a.ty0), fy1), y1 = max(min(fy1, a.ty1), y0);
 
-    int tile_count = rect_tiles;
+    int tile_count = (x1 - x0) * (y1 - y0);
     if (a.tile_based_culling) { // reference stopthepop_common.cuh:176-262
         tile_count = 0;
-        for (int y = y0; y < y1; y++)
-            for (int x = x0; x < x1; x++) {
+        int full_count = 0;
+        for (int y = fy0; y < fy1; y++)
+            for (int x = fx0; x < fx1; x++) {
                 const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
                 const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
                 float2 mp;
                 const float f = max_contrib_power_rect(co, mean2D, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), mp);
-                tile_count += (f <= thr) ? 1 : 0;
+                const int hit = (f <= thr) ? 1 : 0;
+                full_count += hit;
+                tile_count += (y >= y0 && y < y1) ? hit : 0;
             }
+        if (full_count == 0) return;
     }
-    if (tile_count == 0) return;
 
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
     if (a.colors_precomp == nullptr) sh_to_rgb(idx, a.D, a.M, mean, cam, a.shs, a.g.clamped, a.g.rgb);

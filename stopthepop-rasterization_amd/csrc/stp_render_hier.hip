@@ -1,0 +1,41 @@
+// stp_render_hier.hip -- dispatch of the hierarchical kernel over the queue-size ladder
+// (reference forward.cu:445-494, backward.cu:739-767); the kernels themselves are instantiated in
+// slices by stp_render_hier_inst.hip.
+#include "stp_internal.h"
+#include "stp_blend.h"
+
+namespace stp {
+
+#define STP_DECL(name) hipError_t name(const FrameParams& f, const RenderArgs& a, hipStream_t st, bool* handled)
+STP_DECL(launch_hier_fwd_mid8);
+STP_DECL(launch_hier_bwd_mid8);
+#ifndef STP_FASTBUILD
+STP_DECL(launch_hier_fwd_mid12);
+STP_DECL(launch_hier_fwd_mid20);
+STP_DECL(launch_hier_bwd_mid12);
+STP_DECL(launch_hier_bwd_mid20);
+#endif
+#undef STP_DECL
+
+static hipError_t dispatch(bool backward, const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err)
+{
+    const int head = f.s.queue_per_pixel, mid = f.s.queue_tile_2x2;
+    bool handled = false, mid_ok = false;
+    hipError_t e = hipErrorInvalidValue;
+    if (mid == 8) { mid_ok = true; e = backward ? launch_hier_bwd_mid8(f, a, st, &handled) : launch_hier_fwd_mid8(f, a, st, &handled); }
+#ifndef STP_FASTBUILD
+    else if (mid == 12) { mid_ok = true; e = backward ? launch_hier_bwd_mid12(f, a, st, &handled) : launch_hier_fwd_mid12(f, a, st, &handled); }
+    else if (mid == 20) { mid_ok = true; e = backward ? launch_hier_bwd_mid20(f, a, st, &handled) : launch_hier_fwd_mid20(f, a, st, &handled); }
+#endif
+    if (handled) return e;
+    if (err) {
+        if (!mid_ok) *err = "Not supported mid queue size" + (backward ? " " + std::to_string(mid) : std::string());
+        else *err = "Not supported head queue size" + (backward ? " " + std::to_string(head) : std::string());
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_hier_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err) { return dispatch(false, f, a, st, err); }
+hipError_t launch_hier_bwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err) { return dispatch(true, f, a, st, err); }
+
+} // namespace stp

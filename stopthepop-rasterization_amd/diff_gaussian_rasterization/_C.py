@@ -54,6 +54,8 @@ def _load():
     L.stp_backward.restype = ci
     L.stp_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, ctypes.POINTER(StpSettings), vp, vp, vp, vp, vp, cf, vp, vp,
                                vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp] + [vp] * 9 + [ci, vp]
+    L.stp_backward_phases.restype = ci
+    L.stp_backward_phases.argtypes = [ci] + L.stp_backward.argtypes
     L.stp_mark_visible.restype = ci
     L.stp_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
     L.stp_last_error.restype = ctypes.c_char_p
@@ -187,9 +189,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, tan_fovx, tan_fovy,
                                  pixel_colors, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, settings_dict, debug):
+                                 imageBuffer, settings_dict, debug, phases=3, partial=None):
     """== RasterizeGaussiansBackwardCUDA (reference rasterize_points.cu:140-232).
-    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)."""
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
+
+    Extension for tile-row sharding (not in the reference): phases=1 runs only the render half and
+    returns the four per-Gaussian partial sums (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors);
+    phases=2 takes those four (after the caller's all-reduce) as `partial` and runs the preprocess half."""
     L = _load()
     _require_gpu(means3D)
     dev = means3D.device
@@ -197,9 +203,14 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 else 0
     z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors = z(P, 3), z(P, 3), z(P, 3)
-    dL_dconic, dL_dopacity, dL_dcov3D = z(P, 2, 2), z(P, 1), z(P, 6)
-    dL_dsh, dL_dscales, dL_drotations = z(P, M, 3), z(P, 3), z(P, 4)
+    if partial is not None:
+        dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors = partial
+    else:
+        dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity = z(P, 3), z(P, 3), z(P, 2, 2), z(P, 1)
+    if phases & 2:
+        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 3), z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+    else:
+        dL_dmeans3D = dL_dcov3D = dL_dsh = dL_dscales = dL_drotations = None
     s = settings_from_dict(settings_dict)
     if P != 0:
         t = [_prep(x, dev) for x in (background, means3D, sh, colors, opacities, scales, rotations, cov3D_precomp,
@@ -207,15 +218,17 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
         bg_, m3_, sh_, col_, op_, sc_, ro_, c3_, vm_, pm_, inv_, cam_, pix_, dl_ = t
         radii_ = radii.contiguous()
         with torch.cuda.device(dev):
-            rc = L.stp_backward(P, int(degree), M, int(R), _ptr(bg_), W, H, ctypes.byref(s), _ptr(m3_), _ptr(sh_),
-                                _ptr(op_), _ptr(col_), _ptr(sc_), ctypes.c_float(scale_modifier), _ptr(ro_), _ptr(c3_),
-                                _ptr(vm_), _ptr(pm_), _ptr(inv_), _ptr(cam_), ctypes.c_float(tan_fovx),
-                                ctypes.c_float(tan_fovy), _ptr(pix_), _ptr(radii_), _ptr(geomBuffer), _ptr(binningBuffer),
-                                _ptr(imageBuffer), _ptr(dl_), _ptr(dL_dmeans2D), _ptr(dL_dconic), _ptr(dL_dopacity),
-                                _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales),
-                                _ptr(dL_drotations), int(bool(debug)), _stream_ptr(dev))
+            rc = L.stp_backward_phases(int(phases), P, int(degree), M, int(R), _ptr(bg_), W, H, ctypes.byref(s), _ptr(m3_),
+                                       _ptr(sh_), _ptr(op_), _ptr(col_), _ptr(sc_), ctypes.c_float(scale_modifier), _ptr(ro_),
+                                       _ptr(c3_), _ptr(vm_), _ptr(pm_), _ptr(inv_), _ptr(cam_), ctypes.c_float(tan_fovx),
+                                       ctypes.c_float(tan_fovy), _ptr(pix_), _ptr(radii_), _ptr(geomBuffer),
+                                       _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dl_), _ptr(dL_dmeans2D), _ptr(dL_dconic),
+                                       _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
+                                       _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)), _stream_ptr(dev))
         if rc < 0:
             _raise_last(rc)
+    if phases == 1:
+        return dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

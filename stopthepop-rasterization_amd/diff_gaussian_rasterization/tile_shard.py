@@ -1,0 +1,154 @@
+"""Tile-row sharding of ONE frame across the GPUs of a node (BASELINE.json north_star / SURVEY.md 8(e)).
+
+After binning, screen tiles are independent, so rank g of G owns the tile rows
+[g*ceil(Ty/G), min(Ty, (g+1)*ceil(Ty/G))).  Every rank holds the full Gaussian set and runs the
+per-Gaussian preprocess on all of it (cheap, HBM-streaming), but bins, sorts and blends only the tiles
+of its rows (StpSettings.tile_y0/tile_y1).  Exchange steps:
+
+  forward  : the image strips are gathered to rank 0 (`dist.gather` = grouped point-to-point
+             send/recv in RCCL: every peer->root transfer rides its own xGMI link; a ring would be
+             bound by one link) -- or all-gathered when every rank needs the frame;
+  backward : the render half runs on the rank's rows only and yields PARTIAL per-Gaussian sums
+             (dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor = 11 floats per Gaussian); they are linear
+             inputs of the per-Gaussian backward, so ONE all-reduce(sum) of a packed (P,11) buffer precedes
+             the (replicated) preprocess half.  The forward's per-Gaussian state is identical on all ranks
+             because visibility is decided on the full frame.
+
+No reference counterpart exists (the reference is single-GPU); the pure partition/assembly logic below is
+device-agnostic and is exercised by world_size-2 gloo tests on CPU.
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import torch
+
+from . import _C
+
+
+def tile_rows(height: int, tile: int = 16) -> int:
+    return (height + tile - 1) // tile
+
+
+def row_partition(n_rows: int, world: int) -> List[Tuple[int, int]]:
+    """[(y0, y1)] per rank: contiguous blocks of ceil(n_rows/world) rows, last ranks may be short/empty."""
+    per = (n_rows + world - 1) // world
+    return [(min(n_rows, r * per), min(n_rows, (r + 1) * per)) for r in range(world)]
+
+
+def strip_pixels(rows: Tuple[int, int], height: int, tile: int = 16) -> Tuple[int, int]:
+    """Pixel-row interval [py0, py1) covered by a tile-row interval."""
+    return min(height, rows[0] * tile), min(height, rows[1] * tile)
+
+
+def pack_strip(image: torch.Tensor, rows: Tuple[int, int], rows_max: int, tile: int = 16) -> torch.Tensor:
+    """(3,H,W) -> contiguous (3, rows_max*tile, W) strip of this rank's pixel rows, zero padded."""
+    C, H, W = image.shape
+    py0, py1 = strip_pixels(rows, H, tile)
+    out = image.new_zeros((C, rows_max * tile, W))
+    if py1 > py0:
+        out[:, : py1 - py0, :] = image[:, py0:py1, :]
+    return out
+
+
+def assemble(strips: List[torch.Tensor], parts: List[Tuple[int, int]], height: int, tile: int = 16) -> torch.Tensor:
+    """Inverse of pack_strip over all ranks -> (3,H,W)."""
+    C, _, W = strips[0].shape
+    out = strips[0].new_zeros((C, height, W))
+    for strip, rows in zip(strips, parts):
+        py0, py1 = strip_pixels(rows, height, tile)
+        if py1 > py0:
+            out[:, py0:py1, :] = strip[:, : py1 - py0, :]
+    return out
+
+
+def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, dst: int = 0, to_all: bool = False):
+    """Exchange step of the forward.  Returns the assembled (3,H,W) frame on `dst` (every rank if to_all),
+    None elsewhere."""
+    H = local_image.shape[1]
+    rows_max = max(1, max(b - a for a, b in parts))
+    strip = pack_strip(local_image, parts[rank], rows_max)
+    if to_all:
+        bufs = [torch.empty_like(strip) for _ in range(world)]
+        dist.all_gather(bufs, strip)
+        return assemble(bufs, parts, H)
+    bufs = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
+    dist.gather(strip, bufs, dst=dst)
+    return assemble(bufs, parts, H) if rank == dst else None
+
+
+def pack_partials(dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors) -> torch.Tensor:
+    """(P,3),(P,2,2),(P,1),(P,3) -> one contiguous (P,11) buffer for a single all-reduce."""
+    P = dL_dmeans2D.shape[0]
+    return torch.cat([dL_dmeans2D.reshape(P, 3), dL_dconic.reshape(P, 4), dL_dopacity.reshape(P, 1),
+                      dL_dcolors.reshape(P, 3)], dim=1).contiguous()
+
+
+def unpack_partials(buf: torch.Tensor):
+    P = buf.shape[0]
+    return (buf[:, 0:3].contiguous(), buf[:, 3:7].contiguous().reshape(P, 2, 2), buf[:, 7:8].contiguous(),
+            buf[:, 8:11].contiguous())
+
+
+class _ShardedRasterize(torch.autograd.Function):
+    """rasterize_gaussians for one rank's tile rows + the two exchange steps."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard):
+        dist, rank, world, parts, to_all = shard
+        sdict = dict(rs.settings.to_dict())
+        sdict["_tile_rows"] = parts[rank]
+        args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, sdict, rs.render_depth, rs.debug)
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        ctx.rs, ctx.sdict, ctx.shard, ctx.num_rendered = rs, sdict, shard, num_rendered
+        ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
+                              geomBuffer, binningBuffer, imgBuffer)
+        full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
+        ctx.mark_non_differentiable(radii)
+        # every rank returns a (3,H,W) tensor: the assembled frame where it is available, else the local strip image
+        return (full if full is not None else color), radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs, sdict = ctx.rs, ctx.sdict
+        dist, rank, world, parts, to_all = ctx.shard
+        (colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color, geomBuffer,
+         binningBuffer, imgBuffer) = ctx.saved_tensors
+        args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+                rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
+                rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, sdict, rs.debug)
+        partial = _C.rasterize_gaussians_backward(*args, phases=1)
+        buf = pack_partials(*partial)
+        dist.all_reduce(buf)  # sum over ranks: 44 bytes per Gaussian
+        out = _C.rasterize_gaussians_backward(*args, phases=2, partial=unpack_partials(buf))
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations) = out
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None, None)
+
+
+class TileRowShardedRasterizer(torch.nn.Module):
+    """Drop-in for GaussianRasterizer when one frame is split over `world` ranks by tile row.
+    forward(...) has GaussianRasterizer.forward's signature; it returns (image, radii) where `image` is the
+    assembled frame on rank 0 (on every rank with to_all=True) and this rank's strip image elsewhere.
+    The loss must be evaluated so that each rank back-propagates the gradient of ITS rows (e.g. a per-pixel
+    loss evaluated redundantly, or dL/dimage scattered from rank 0)."""
+
+    def __init__(self, raster_settings, dist, rank: int, world: int, to_all: bool = False):
+        super().__init__()
+        self.raster_settings = raster_settings
+        self.parts = row_partition(tile_rows(raster_settings.image_height), world)
+        self.shard = (dist, rank, world, self.parts, to_all)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        empty = lambda t: torch.Tensor([]) if t is None else t
+        return _ShardedRasterize.apply(means3D, means2D, empty(shs), empty(colors_precomp), opacities, empty(scales),
+                                       empty(rotations), empty(cov3D_precomp), self.raster_settings, self.shard)
