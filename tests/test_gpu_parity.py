@@ -1,0 +1,230 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the public drop-in API (GaussianRasterizer ->
+autograd -> _C -> C ABI of libstp_raster.so), against the CPU oracle on the same seeded inputs.
+
+Tolerances (north_star: "within a stated fp32 tolerance, PSNR >= 60 dB"):
+  * integer / index work (radii, tile counts, offsets, 64-bit sort keys, sorted lists, tile ranges): bit-exact;
+  * per-Gaussian fp32 state (means2D, conics, depths, Sigma^-1 ...): bit-exact except values downstream of
+    logf (tight_opacity_bounding extents), where host and device libm may differ by an ulp;
+  * image: max-abs <= 2e-6 and PSNR >= 100 dB (the blend loops may contract a*b+c, expf differs by an ulp);
+  * gradients: max-abs error <= 1e-4 of the largest entry (atomic / LDS-atomic summation order).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import FULL_STP, GpuRun, max_abs, oracle_run, psnr, settings_dict
+from diff_gaussian_rasterization import scenes
+
+pytestmark = pytest.mark.gpu
+
+GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dcolors")
+
+
+def _rel(a, b):
+    return max_abs(a, b) / max(float(np.max(np.abs(b))), 1e-30)
+
+
+def check_against_oracle(scene, sd, backward=True, exact_state=True):
+    g = GpuRun(scene, sd, backward=backward)
+    f, og = oracle_run(scene, sd, backward=backward)
+    assert g.num_rendered == f.num_rendered
+    assert np.array_equal(g.radii, f.radii)
+    assert np.array_equal(g.geom_array("tiles_touched").view(np.uint32), f.array("tiles_touched"))
+    assert np.array_equal(g.geom_array("point_offsets").view(np.uint32), f.array("point_offsets"))
+    vis = f.radii > 0
+    for nm, per in (("depths", 1), ("means2D", 2), ("conic_opacity", 4), ("cov3D", 6)):
+        a, b = g.geom_array(nm).reshape(-1, per)[vis], f.array(nm).reshape(-1, per)[vis]
+        if exact_state:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), nm
+        else:
+            assert _rel(a, b) < 1e-6, nm
+    if f.num_rendered:
+        assert np.array_equal(g.binning_array("keys"), f.array("keys"))
+        assert np.array_equal(g.binning_array("point_list"), f.array("point_list"))
+        assert np.array_equal(g.image_array("ranges").view(np.uint32), f.array("ranges"))
+    assert max_abs(g.color, f.color) <= 2e-6
+    assert psnr(g.color, f.color) >= 100.0
+    if backward:
+        for k in GRAD_KEYS:
+            if g.grads.get(k) is None or og.get(k) is None or og[k].size == 0:
+                continue
+            a, b = g.grads[k], og[k]
+            if k == "dL_dmeans2D":
+                a, b = a[:, :2], b[:, :2]
+            assert _rel(a, b) < 1e-4, k
+    return g, f
+
+
+C1 = dict(P=1000, W=256, H=256, sigma_min=1.0, sigma_max=12.0, seed=1)
+DENSE = dict(P=6000, W=96, H=80, sigma_min=2.0, sigma_max=14.0, seed=11, camera="orbit")
+
+
+@pytest.mark.parametrize("sd", [
+    settings_dict(0), settings_dict(0, order=1), settings_dict(0, order=2), settings_dict(0, order=3),
+    settings_dict(2, per_pixel=16), settings_dict(3), settings_dict(3, h44=True), settings_dict(**FULL_STP)],
+    ids=["global_z", "global_dist", "ptd_center", "ptd_max", "kbuffer16", "hier", "hier_cull", "full_stp"])
+def test_c1_all_modes(sd):
+    """BASELINE config C1 (1k Gaussians, 256x256) in every sort mode / order, forward + backward."""
+    check_against_oracle(scenes.make_scene(**C1), sd)
+
+
+@pytest.mark.parametrize("sd", [
+    settings_dict(0), settings_dict(2, per_pixel=16), settings_dict(2, per_pixel=4, ewa=True), settings_dict(3),
+    settings_dict(3, h44=True), settings_dict(**FULL_STP), settings_dict(0, rect=True, tight=True, tbc=True),
+    settings_dict(**{**FULL_STP, "ewa": True})],
+    ids=["global", "kbuffer16", "kbuffer4_ewa", "hier", "hier_cull", "full_stp", "global_all_culling", "full_stp_ewa"])
+def test_dense_scene(sd):
+    """~700 Gaussians per tile, off-axis rotated camera: the regime where the resorting queues actually
+    reorder and hierarchical != exact sort."""
+    exact = not (sd["culling_settings"]["tight_opacity_bounding"])
+    check_against_oracle(scenes.make_scene(**DENSE), sd, exact_state=exact)
+
+
+@pytest.mark.parametrize("head,mid", [(8, 8), (16, 8), (4, 12), (8, 12), (16, 20), (4, 20)])
+def test_hier_queue_sizes(head, mid):
+    check_against_oracle(scenes.make_scene(**DENSE), settings_dict(3, per_pixel=head, tile_2x2=mid, h44=True))
+
+
+@pytest.mark.parametrize("window", [1, 2, 4, 8, 12, 20, 24])
+def test_kbuffer_windows(window):
+    check_against_oracle(scenes.make_scene(P=3000, W=80, H=64, sigma_min=2.0, sigma_max=12.0, seed=5), settings_dict(2, per_pixel=window))
+
+
+def test_ppx_full_forward_and_no_backward():
+    sc = scenes.make_scene(P=2500, W=48, H=32, sigma_min=2.0, sigma_max=12.0, seed=5, camera="orbit")  # > 1024 per tile
+    check_against_oracle(sc, settings_dict(1), backward=False)
+    with pytest.raises(RuntimeError, match="Backward not supported for full per-pixel sort"):
+        GpuRun(sc, settings_dict(1), backward=True)
+
+
+def test_unsupported_queue_sizes_raise():
+    sc = scenes.make_scene(P=100, W=32, H=32, sigma_min=1.0, sigma_max=4.0, seed=2)
+    with pytest.raises(RuntimeError, match="Not supported head queue size"):
+        GpuRun(sc, settings_dict(3, per_pixel=5), backward=False)
+    with pytest.raises(RuntimeError, match="Not supported mid queue size"):
+        GpuRun(sc, settings_dict(3, tile_2x2=16), backward=False)
+    with pytest.raises(RuntimeError, match="Not supported head queue size"):  # 12 exists only in the backward ladder
+        GpuRun(sc, settings_dict(3, per_pixel=12), backward=False)
+
+
+def test_precomputed_colors_and_rgb_gradient():
+    check_against_oracle(scenes.make_scene(**{**C1, "use_sh": False, "camera": "orbit"}), settings_dict(3, h44=True))
+
+
+def test_odd_image_size_and_tiny_inputs():
+    check_against_oracle(scenes.make_scene(P=1, W=37, H=19, sigma_min=3.0, sigma_max=3.1, seed=4), settings_dict(3))
+    check_against_oracle(scenes.make_scene(P=300, W=1063 // 8, H=97, sigma_min=1.0, sigma_max=9.0, seed=4), settings_dict(**FULL_STP))
+
+
+def test_everything_culled_and_empty_input():
+    import diff_gaussian_rasterization as dgr
+    sc = scenes.make_scene(P=64, W=48, H=32, sigma_min=1.0, sigma_max=4.0, seed=2)
+    sc.means3D[:, 2] = 0.1  # behind the near plane
+    g = GpuRun(sc, settings_dict(3), backward=True)
+    assert g.num_rendered == 0 and not g.radii.any()
+    assert np.allclose(g.color, np.asarray(sc.bg).reshape(3, 1, 1))
+    assert all(v is None or not np.any(v) for v in g.grads.values())
+    # P == 0 (reference rasterize_points.cu:93): zero image, no launch
+    dev = torch.device("cuda:0")
+    z = lambda *s: torch.zeros(*s, device=dev)
+    rs = dgr.GaussianRasterizationSettings(32, 48, 0.5, 0.5, z(3), 1.0, torch.eye(4, device=dev), torch.eye(4, device=dev),
+                                           torch.eye(4, device=dev), 0, z(3), False, dgr.ExtendedSettings(), False, False)
+    color, radii = dgr.GaussianRasterizer(rs)(z(0, 3), z(0, 3), z(0, 1), colors_precomp=z(0, 3), scales=z(0, 3), rotations=z(0, 4))
+    assert color.shape == (3, 32, 48) and not color.any() and radii.numel() == 0
+
+
+def test_mark_visible_matches_oracle():
+    import diff_gaussian_rasterization as dgr
+    from oracle import oracle as orc
+    sc = scenes.make_scene(P=5000, W=64, H=64, sigma_min=1.0, sigma_max=4.0, seed=6, camera="orbit")
+    sc.means3D[::7] = sc.campos
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.tensor(a, device=dev)
+    rs = dgr.GaussianRasterizationSettings(64, 64, sc.tanfovx, sc.tanfovy, t(sc.bg), 1.0, t(sc.viewmatrix), t(sc.projmatrix),
+                                           t(sc.inv_viewprojmatrix), 3, t(sc.campos), False, dgr.ExtendedSettings(), False, False)
+    vis = dgr.GaussianRasterizer(rs).markVisible(t(sc.means3D)).cpu().numpy()
+    assert vis.dtype == np.bool_ and np.array_equal(vis, orc.mark_visible(sc.means3D, sc.viewmatrix, sc.projmatrix))
+
+
+def test_debug_flag_synchronises_and_gives_the_same_frame():
+    sc = scenes.make_scene(**DENSE)
+    a = GpuRun(sc, settings_dict(**FULL_STP), backward=False)
+    b = GpuRun(sc, settings_dict(**FULL_STP), backward=False, debug=True)
+    assert np.array_equal(a.color, b.color)
+
+
+@pytest.mark.parametrize("name", ["c1_global", "dense_hier_full", "dense_kbuffer"])
+def test_golden_fixtures(name):
+    from golden.make_golden import CASES
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".npz"))
+    case = CASES[name]
+    g = GpuRun(scenes.make_scene(**case["scene"]), case["settings"], backward=True)
+    assert g.num_rendered == int(ref["num_rendered"]) and np.array_equal(g.radii, ref["radii"])
+    assert psnr(g.color, ref["color"]) >= 100.0
+    for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales"):
+        assert _rel(g.grads[k], ref[k]) < 1e-4
+
+
+def test_tile_row_windows_paste_to_the_full_frame():
+    """The sharding primitive on one GPU: disjoint tile-row windows reproduce the full frame bit for bit."""
+    sc = scenes.make_scene(P=20000, W=320, H=240, sigma_min=1.0, sigma_max=10.0, seed=8, camera="orbit")
+    sd = settings_dict(**FULL_STP)
+    full = GpuRun(sc, sd, backward=False)
+    img = np.zeros_like(full.color)
+    for rows in ((0, 4), (4, 9), (9, 15)):
+        part = GpuRun(sc, sd, backward=False, tile_rows=rows)
+        assert np.array_equal(part.radii, full.radii)
+        img[:, rows[0] * 16:rows[1] * 16] = part.color[:, rows[0] * 16:rows[1] * 16]
+    assert np.array_equal(img, full.color)
+
+
+# ---------------------------------------------------------------- BASELINE-size property tests
+@pytest.fixture(scope="module")
+def c2_scene():
+    return scenes.config("C2")
+
+
+def test_c2_full_size_properties(c2_scene):
+    """Full 1M-Gaussian 1080p frame (the oracle would take minutes): size-independent properties."""
+    sd = settings_dict(**FULL_STP)
+    g = GpuRun(c2_scene, sd, backward=True)
+    R = g.num_rendered
+    tiles = g.geom_array("tiles_touched").view(np.uint32)
+    assert int(tiles.astype(np.int64).sum()) == R                       # checksum of the duplicate count
+    assert np.array_equal(np.cumsum(tiles.astype(np.int64)).astype(np.uint32), g.geom_array("point_offsets").view(np.uint32))
+    keys = g.binning_array("keys")
+    T = ((c2_scene.W + 15) // 16) * ((c2_scene.H + 15) // 16)
+    bit = int(np.ceil(np.log2(T + 1)))
+    masked = keys & np.uint64((1 << (32 + bit)) - 1)
+    assert np.all(masked[1:] >= masked[:-1])                            # sortedness on the sorted bit range
+    assert np.array_equal(np.sort(g.binning_array("keys_unsorted")), np.sort(keys))   # the sort is a permutation
+    ranges = g.image_array("ranges").view(np.uint32).reshape(-1, 2)
+    valid_tiles = (keys >> np.uint64(32)) < T
+    assert int((ranges[:, 1] - ranges[:, 0]).astype(np.int64).sum()) == int(valid_tiles.sum())  # ranges tile the valid part
+    fT = g.image_array("final_T")
+    assert np.all(fT >= 0) and np.all(fT <= 1) and np.isfinite(g.color).all()
+    assert all(np.isfinite(v).all() for v in g.grads.values() if v is not None)
+    # determinism of the forward, and linearity of the backward in dL/dimage
+    g2 = GpuRun(c2_scene, sd, backward=False)
+    assert np.array_equal(g.color, g2.color)
+    scaled = scenes.config("C2")
+    scaled.dL_dout = scaled.dL_dout * np.float32(2.0)
+    g3 = GpuRun(scaled, sd, backward=True)
+    assert _rel(g3.grads["dL_dmeans3D"], 2.0 * g.grads["dL_dmeans3D"]) < 1e-4
+    assert _rel(g3.grads["dL_dsh"], 2.0 * g.grads["dL_dsh"]) < 1e-4
+
+
+def test_c2_tile_rows_against_oracle(c2_scene):
+    """A window of tile rows of the FULL C2 frame (1M Gaussians preprocessed, ~6% of the tiles blended), in both C2
+    variants, against the oracle on the same window: image, radii and the render-half gradients."""
+    for sd in (settings_dict(**FULL_STP), settings_dict(3)):
+        rows = (32, 36)
+        g = GpuRun(c2_scene, sd, backward=True, tile_rows=rows)
+        f, og = oracle_run(c2_scene, sd, backward=True, tile_rows=rows)
+        assert g.num_rendered == f.num_rendered and np.array_equal(g.radii, f.radii)
+        sl = slice(rows[0] * 16, rows[1] * 16)
+        assert psnr(g.color[:, sl], f.color[:, sl]) >= 100.0 and max_abs(g.color[:, sl], f.color[:, sl]) <= 2e-6
+        for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh"):
+            assert _rel(g.grads[k], og[k]) < 1e-4, k
