@@ -225,22 +225,32 @@ def main():
 
 def cpu_baseline(scene, sdict, gy, fwd_only, rows):
     """Oracle (our CPU restatement, OpenMP over all host cores) on a bounded sample of the same frame:
-    a centred window of tile rows, time extrapolated linearly to the full frame."""
+    a centred window of tile rows, sized by a 2-row calibration run so that the sample takes ~15 s, the time
+    extrapolated linearly to the full frame."""
     from oracle import oracle as orc
     cores = orc.num_threads()
+
+    def run(r):
+        y0 = max(0, (gy - r) // 2)
+        t0 = time.perf_counter()
+        f = orc.forward_scene(scene, sdict, tile_rows=(y0, y0 + r))
+        if not fwd_only:
+            f.backward(scene.dL_dout)
+        dt = time.perf_counter() - t0
+        f.free()
+        return y0, dt
+
     if rows <= 0:
-        rows = max(1, min(gy, int(round(gy * min(1.0, 2.0e5 / max(scene.P, 1))))))  # ~20 s of CPU work at C2
-    y0 = max(0, (gy - rows) // 2)
-    t0 = time.perf_counter()
-    f = orc.forward_scene(scene, sdict, tile_rows=(y0, y0 + rows))
-    if not fwd_only:
-        f.backward(scene.dL_dout)
-    dt = time.perf_counter() - t0
-    f.free()
+        cal_rows = min(2, gy)
+        _, t_cal = run(cal_rows)                       # includes the per-Gaussian stages of all P once
+        _, t_cal0 = run(0) if False else (0, 0.0)
+        per_row = max(t_cal / cal_rows, 1e-3)
+        rows = int(max(cal_rows, min(gy, round(15.0 / per_row))))
+    y0, dt = run(rows)
     est_frame_s = dt * gy / rows
     return {"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"tile rows {y0}..{y0 + rows - 1} of {gy} of the same frame ({'fwd' if fwd_only else 'fwd+bwd'}), "
-                      f"{dt:.1f} s measured, extrapolated x{gy / rows:.2f}"}
+                      f"{dt:.1f} s measured on {cores} threads, extrapolated x{gy / rows:.2f}"}
 
 
 if __name__ == "__main__":
