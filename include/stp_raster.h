@@ -144,9 +144,9 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
 
 /* Stage timer, the counterpart of the reference's `Timer` (rasterizer_impl.h:77-147; stages
    "Preprocess","Duplicate","Sort","Render", rasterizer_impl.cu:248) plus "BwdRender","BwdPreprocess".
-   When enabled, every forward/backward records hipEvents around its stages on the call's stream;
-   stp_timing_read synchronises those events and returns the last call's milliseconds
-   (6 floats, unmeasured stages are -1). */
+   While enabled, every forward/backward records hipEvents around its stages on the call's stream (no extra
+   host synchronisation); stp_timing_read waits for the recorded events and returns the MEAN milliseconds per
+   stage over the calls since stp_timing_enable(1) (6 floats, unmeasured stages are -1). */
 void stp_timing_enable(int enabled);
 int stp_timing_read(float* ms6);
 

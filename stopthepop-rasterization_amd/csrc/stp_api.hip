@@ -17,27 +17,66 @@ namespace stp {
 static thread_local std::string g_last_error;
 static bool g_timing = false;
 
-struct StageTimer { // counterpart of the reference's Timer (rasterizer_impl.h:77-147)
-    hipEvent_t ev[8] = {};
-    bool have[8] = {};
+// Counterpart of the reference's Timer (rasterizer_impl.h:77-147): hipEvents around the stages of every call,
+// recorded on the call's stream.  A ring of event sets lets a whole timed region run without any extra host
+// synchronisation; spans are harvested lazily and averaged (mean over the calls since stp_timing_enable(1)).
+struct StageTimer {
+    static constexpr int SETS = 64, EV = 8; // events 0..4: forward stage boundaries, 5..7: backward
+    struct Set { hipEvent_t ev[EV]; bool have[EV]; bool used; };
+    Set sets[SETS] = {};
     bool created = false;
+    int cur = 0;
+    double sum[6] = {};
+    long cnt[6] = {};
     void ensure()
     {
         if (created) return;
-        for (auto& e : ev) (void)hipEventCreate(&e);
+        for (auto& s : sets) { for (auto& e : s.ev) (void)hipEventCreate(&e); for (auto& h : s.have) h = false; s.used = false; }
         created = true;
+    }
+    void harvest(Set& s)
+    {
+        if (!s.used) return;
+        static const int from[6] = {0, 1, 2, 3, 5, 6}, to[6] = {1, 2, 3, 4, 6, 7};
+        for (int i = 0; i < 6; i++) {
+            if (!(s.have[from[i]] && s.have[to[i]])) continue;
+            if (hipEventSynchronize(s.ev[to[i]]) != hipSuccess) continue;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, s.ev[from[i]], s.ev[to[i]]) == hipSuccess) { sum[i] += ms; cnt[i]++; }
+        }
+        for (auto& h : s.have) h = false;
+        s.used = false;
+    }
+    void begin_forward()
+    {
+        if (!g_timing) return;
+        ensure();
+        cur = (cur + 1) % SETS;
+        harvest(sets[cur]); // only blocks if the ring wrapped around unharvested work
+        sets[cur].used = true;
+    }
+    void begin_backward()
+    {
+        if (!g_timing) return;
+        ensure();
+        sets[cur].used = true;
+        for (int i = 5; i < EV; i++) sets[cur].have[i] = false;
     }
     void mark(int i, hipStream_t st)
     {
         if (!g_timing) return;
         ensure();
-        (void)hipEventRecord(ev[i], st);
-        have[i] = true;
+        (void)hipEventRecord(sets[cur].ev[i], st);
+        sets[cur].have[i] = true;
     }
-    void reset_fwd() { for (int i = 0; i < 5; i++) have[i] = false; }
-    void reset_bwd() { for (int i = 5; i < 8; i++) have[i] = false; }
+    void reset()
+    {
+        if (created) for (auto& s : sets) { for (auto& h : s.have) h = false; s.used = false; }
+        for (auto& v : sum) v = 0.0;
+        for (auto& c : cnt) c = 0;
+    }
 };
-static StageTimer g_timer; // events 0..4: forward stage boundaries, 5..7: backward stage boundaries
+static StageTimer g_timer;
 
 static int fail(int code, const std::string& msg)
 {
@@ -216,25 +255,21 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
     return find_name(names, n, name, offset, count);
 }
 
-void stp_timing_enable(int enabled) { g_timing = enabled != 0; }
+void stp_timing_enable(int enabled)
+{
+    g_timing = enabled != 0;
+    if (g_timing) g_timer.reset();
+}
 
 int stp_timing_read(float* ms6)
 {
     if (!ms6) return fail(STP_ERR_INVALID_ARGUMENT, "null output");
     for (int i = 0; i < 6; i++) ms6[i] = -1.0f;
     if (!g_timer.created) return 0;
-    auto span = [&](int from, int to, float* out) {
-        if (!(g_timer.have[from] && g_timer.have[to])) return;
-        if (hipEventSynchronize(g_timer.ev[to]) != hipSuccess) return;
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, g_timer.ev[from], g_timer.ev[to]) == hipSuccess) *out = ms;
-    };
-    span(0, 1, &ms6[0]); // Preprocess (+ scan + read-back)
-    span(1, 2, &ms6[1]); // Duplicate
-    span(2, 3, &ms6[2]); // Sort (+ ranges)
-    span(3, 4, &ms6[3]); // Render
-    span(5, 6, &ms6[4]); // BwdRender
-    span(6, 7, &ms6[5]); // BwdPreprocess
+    for (auto& s : g_timer.sets) g_timer.harvest(s);
+    // 0 Preprocess (+scan+read-back), 1 Duplicate, 2 Sort (+ranges), 3 Render, 4 BwdRender, 5 BwdPreprocess
+    for (int i = 0; i < 6; i++)
+        if (g_timer.cnt[i] > 0) ms6[i] = (float)(g_timer.sum[i] / (double)g_timer.cnt[i]);
     return 0;
 }
 
@@ -276,7 +311,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
     ImageState img = carve_image(img_ptr, N, T, nullptr);
 
-    g_timer.reset_fwd();
+    g_timer.begin_forward();
     g_timer.mark(0, st);
     STP_TRY(hipMemsetAsync(g.status, 0, 64 * sizeof(uint32_t), st), "memset status");
     STP_TRY(launch_preprocess(f, g, radii, st), "preprocess launch");
@@ -351,7 +386,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     bw.dL_dscale = dL_dscale; bw.dL_drot = dL_drot;
 
     if (phases & 1) {
-        g_timer.reset_bwd();
+        g_timer.begin_backward();
         g_timer.mark(5, st);
         std::string err;
         hipError_t e = launch_render_backward(f, g, b, img, bw, st, &err);

@@ -80,24 +80,46 @@ __device__ __forceinline__ bool blend_forward(FwdPixel& p, const float* __restri
     return true;
 }
 
+// same, with the colour already in registers (prefetched when the entry became the queue front)
+__device__ __forceinline__ bool blend_forward_c(FwdPixel& p, const float (&c)[3], float alpha)
+{
+    const float test_T = p.T * (1.0f - alpha);
+    if (test_T < T_THRESHOLD) return false;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) p.C[ch] += c[ch] * alpha * p.T;
+    p.T = test_T;
+    return true;
+}
+
 // Gradient of one blended pair, front-to-back formulation: the colour behind the current entry is
 // reconstructed from the forward image, accum_rec = (final_colour - C_so_far) / T_after.
 // Produces the nine per-Gaussian terms g[0..2] = dL/dcolour, g[3..4] = dL/dmean2D (x,y),
 // g[5..7] = dL/dconic (xx, xy, yy), g[8] = dL/dopacity; the caller decides how they are accumulated.
 // Returns false (and leaves g untouched) when the pixel saturates.
-__device__ __forceinline__ bool blend_backward_terms(BwdPixel& b, const RenderArgs& a, int px, int py, int id, float G, float (&g)[9])
+struct FrontData { float4 co; float2 xy; float c[3]; }; // what a backward blend reads of its Gaussian
+
+__device__ __forceinline__ FrontData load_front(const RenderArgs& a, int id)
 {
-    const float4 co = a.conic_opacity[id];
+    FrontData f;
+    f.co = a.conic_opacity[id];
+    f.xy = a.means2D[id];
+    f.c[0] = a.features[3 * (size_t)id + 0]; f.c[1] = a.features[3 * (size_t)id + 1]; f.c[2] = a.features[3 * (size_t)id + 2];
+    return f;
+}
+
+__device__ __forceinline__ bool blend_backward_terms(BwdPixel& b, const RenderArgs& a, int px, int py, const FrontData& fd, float G, float (&g)[9])
+{
+    const float4 co = fd.co;
     const float alpha = fminf(0.99f, co.w * G);
     const float test_T = b.T * (1.0f - alpha);
     if (test_T < T_THRESHOLD) return false;
-    const float2 xy = a.means2D[id];
+    const float2 xy = fd.xy;
     const float dx = xy.x - (float)px, dy = xy.y - (float)py;
     const float dchannel_dcolor = alpha * b.T;
     float dL_dalpha = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
-        const float c = a.features[3 * (size_t)id + ch];
+        const float c = fd.c[ch];
         b.C[ch] += c * alpha * b.T;
         const float accum_rec = (b.final_color[ch] - b.C[ch]) / test_T;
         dL_dalpha += (c - accum_rec) * b.dL_dpix[ch];
@@ -134,7 +156,8 @@ __device__ __forceinline__ float* grad_slot(const RenderArgs& a, int id, int k)
 __device__ __forceinline__ bool blend_backward(BwdPixel& b, const RenderArgs& a, int px, int py, int id, float G)
 {
     float g[9];
-    if (!blend_backward_terms(b, a, px, py, id, G, g)) return false;
+    const FrontData fd = load_front(a, id);
+    if (!blend_backward_terms(b, a, px, py, fd, G, g)) return false;
 #pragma unroll
     for (int k = 0; k < 9; k++) atomicAdd(grad_slot(a, id, k), g[k]);
     return true;
