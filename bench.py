@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--force-shard", action="store_true", help="use the tile-row sharded path even with one rank (self-test of the exchange code)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -96,10 +97,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_shard:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
 
     import diff_gaussian_rasterization as dgr
@@ -121,7 +123,7 @@ def main():
         prefiltered=False, settings=es, render_depth=False, debug=False)
 
     gy = (scene.H + 15) // 16
-    sharded = world > 1 and args.shard == "tilerows"
+    sharded = (world > 1 or args.force_shard) and args.shard == "tilerows"
     if sharded:
         raster = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
     else:

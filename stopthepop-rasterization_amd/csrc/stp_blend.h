@@ -116,17 +116,21 @@ __device__ __forceinline__ bool blend_backward_terms(BwdPixel& b, const RenderAr
     const float2 xy = fd.xy;
     const float dx = xy.x - (float)px, dy = xy.y - (float)py;
     const float dchannel_dcolor = alpha * b.T;
+    // gradients are compared with a relative tolerance (summation order already differs from the reference's
+    // atomics), so the two quotients use the hardware reciprocal (v_rcp_f32, 1 ulp) instead of IEEE division
+    const float rcp_test_T = __builtin_amdgcn_rcpf(test_T);
+    const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
     float dL_dalpha = 0.0f;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const float c = fd.c[ch];
         b.C[ch] += c * alpha * b.T;
-        const float accum_rec = (b.final_color[ch] - b.C[ch]) / test_T;
+        const float accum_rec = (b.final_color[ch] - b.C[ch]) * rcp_test_T;
         dL_dalpha += (c - accum_rec) * b.dL_dpix[ch];
         g[ch] = dchannel_dcolor * b.dL_dpix[ch];
     }
     dL_dalpha *= b.T;
-    dL_dalpha += (-b.T_final / (1.f - alpha)) * b.bg_dot;
+    dL_dalpha += (-b.T_final * rcp_1ma) * b.bg_dot;
     const float dL_dG = co.w * dL_dalpha;
     const float gdx = G * dx, gdy = G * dy;
     const float dG_ddelx = -gdx * co.x - gdy * co.y;
