@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 1
+#define STP_ABI_VERSION 2
 
 /* Replaces CudaRasterizer::SplattingSettings + SortSettings + SortQueueSizes + CullingSettings
    (rasterizer.h:27-135) and their json parser (rasterizer.h:160-182): the host binding fills this
@@ -49,6 +49,12 @@ typedef struct StpSettings {
        for tile-row sharding of one frame over several GPUs.  tile_y1 <= 0 selects all rows. */
     int32_t tile_y0;
     int32_t tile_y1;
+    /* Extension (not in the reference): hierarchical mode only.  When non-zero the forward also records, per
+       pixel, the order in which it blended its Gaussians (4 bytes per blended pair, 1 KiB per pixel, inside the
+       image buffer); a backward called with the same flag replays that log instead of re-running the resort
+       (the re-sorting backward still handles tiles whose log overflowed).  Results are the same sums in a
+       different order.  Set it for training forwards; leave it 0 for inference. */
+    int32_t record_blend_log;
 } StpSettings;
 
 typedef enum StpStatus {
@@ -131,7 +137,7 @@ int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Sizes of the three scratch buffers (the reference's `required<State>()`, rasterizer_impl.h:68-75). */
 size_t stp_geometry_buffer_size(int P, const StpSettings* settings);
 size_t stp_binning_buffer_size(int R);
-size_t stp_image_buffer_size(int width, int height);
+size_t stp_image_buffer_size(int width, int height); /* without the optional blend log (+ 1 KiB per tile pixel) */
 
 /* Introspection of the (otherwise opaque) scratch buffers, for parity tests and debugging.
    Fills byte offset and element count of a named sub-array; returns 0 or STP_ERR_INVALID_ARGUMENT.

@@ -114,7 +114,7 @@ GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total,
     return g;
 }
 
-ImageState carve_image(char* base, size_t N, size_t T, size_t* total, NamedOffset* names, int* n_names)
+ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* total, NamedOffset* names, int* n_names)
 {
     Carver c(base);
     ImageState s{};
@@ -124,6 +124,10 @@ ImageState carve_image(char* base, size_t N, size_t T, size_t* total, NamedOffse
     s.final_T = c.take<float>(N, &off); note("final_T", off, N);
     s.n_contrib = c.take<uint32_t>(N, &off); note("n_contrib", off, N);
     s.ranges = c.take<uint2>(T, &off); note("ranges", off, 2 * T);
+    if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 4 bytes per pixel
+        s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
+        s.blend_log = c.take<uint32_t>(T * 256 * 256, &off); note("blend_log", off, T * 256 * 256);
+    }
     if (total) *total = c.total();
     if (n_names) *n_names = n;
     return s;
@@ -221,7 +225,7 @@ size_t stp_image_buffer_size(int width, int height)
 {
     size_t total = 0;
     const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-    carve_image(nullptr, (size_t)width * height, T, &total);
+    carve_image(nullptr, (size_t)width * height, T, false, &total);
     return total;
 }
 
@@ -251,7 +255,7 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
 {
     NamedOffset names[8]; int n = 0;
     const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-    carve_image(nullptr, (size_t)width * height, T, nullptr, names, &n);
+    carve_image(nullptr, (size_t)width * height, T, true, nullptr, names, &n);
     return find_name(names, n, name, offset, count);
 }
 
@@ -306,10 +310,12 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
 
     const size_t N = (size_t)width * height, T = (size_t)f.gx * f.gy;
     size_t img_bytes = 0;
-    carve_image(nullptr, N, T, &img_bytes);
+    const bool with_log = uses_blend_log(*settings);
+    carve_image(nullptr, N, T, with_log, &img_bytes);
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
-    ImageState img = carve_image(img_ptr, N, T, nullptr);
+    ImageState img = carve_image(img_ptr, N, T, with_log, nullptr);
+    if (with_log) STP_TRY(hipMemsetAsync(img.tile_flags, 0, T * sizeof(uint32_t), st), "memset tile flags");
 
     g_timer.begin_forward();
     g_timer.mark(0, st);
@@ -377,7 +383,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     const bool with_inv = requires_depth_along_ray(*settings);
     GeometryState g = carve_geometry(geom_buffer, (size_t)P, with_inv, nullptr);
     BinningState b = carve_binning(binning_buffer, (size_t)(R > 0 ? R : 0), nullptr);
-    ImageState img = carve_image(image_buffer, (size_t)width * height, (size_t)f.gx * f.gy, nullptr);
+    ImageState img = carve_image(image_buffer, (size_t)width * height, (size_t)f.gx * f.gy, uses_blend_log(*settings), nullptr);
     if (!radii) radii = g.internal_radii;
 
     BackwardParams bw;

@@ -31,7 +31,14 @@ struct RenderArgs {
     float* dL_dconic;  // P x 4
     float* dL_dopacity;
     float* dL_dcolor;  // P x 3
+    // blend log (training forward -> replay backward): per (tile, wave, k, lane) the list position of the k-th
+    // entry that lane's pixel blended; tile_flags[tile] != 0 marks a tile whose log overflowed
+    uint32_t* blend_log;
+    uint32_t* tile_flags;
+    int flag_mode; // resorting backward: 0 = all tiles, 1 = only tiles with tile_flags != 0
 };
+
+constexpr int BLEND_LOG_DEPTH = 256; // records per pixel the log can hold (4 B each: 1 KiB per pixel)
 
 struct FwdPixel {
     float T;

@@ -17,6 +17,8 @@ constexpr size_t ALIGN = 256; // sub-array alignment inside the scratch buffers
 enum SortMode { MODE_GLOBAL = 0, MODE_FULL = 1, MODE_KBUFFER = 2, MODE_HIER = 3 };
 enum SortOrder { ORDER_Z = 0, ORDER_DISTANCE = 1, ORDER_PTD_CENTER = 2, ORDER_PTD_MAX = 3 };
 
+inline bool uses_blend_log(const StpSettings& s) { return s.record_blend_log != 0 && s.sort_mode == MODE_HIER; }
+
 inline bool requires_depth_along_ray(const StpSettings& s) // reference rasterizer.h:66-71
 {
     return s.sort_mode != MODE_GLOBAL || s.sort_order == ORDER_PTD_CENTER || s.sort_order == ORDER_PTD_MAX;
@@ -62,6 +64,8 @@ struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges 
     float* final_T;      // N
     uint32_t* n_contrib; // N
     uint2* ranges;       // T
+    uint32_t* tile_flags; // T   (only with the blend log)
+    uint32_t* blend_log;  // T * 4 waves * BLEND_LOG_DEPTH * 64 lanes (only with the blend log)
 };
 
 struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
@@ -76,7 +80,7 @@ struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
 struct NamedOffset { const char* name; size_t offset; size_t count; };
 
 GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
-ImageState carve_image(char* base, size_t N, size_t T, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
+ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
 BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
 
 size_t scan_temp_bytes(size_t P);

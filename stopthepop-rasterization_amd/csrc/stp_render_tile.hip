@@ -328,12 +328,15 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
     a.cov3D_inv = g.cov3D_inv; a.features = f.colors_precomp ? f.colors_precomp : g.rgb; // reference rasterizer_impl.cu:367,473
     a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.bg = f.background;
     a.final_T = img.final_T; a.n_contrib = img.n_contrib;
+    a.blend_log = img.blend_log; a.tile_flags = img.tile_flags; a.flag_mode = 0;
     return a;
 }
 
 // implemented in stp_render_hier_fwd.hip / stp_render_hier_bwd.hip / stp_render_full.hip
 hipError_t launch_hier_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
 hipError_t launch_hier_bwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
+hipError_t launch_hier_rec(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
+hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 hipError_t launch_full_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 
 template <bool BACKWARD> static hipError_t launch_kbuffer(const FrameParams& f, const RenderArgs& a, hipStream_t st)
@@ -366,7 +369,7 @@ hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, c
         return hipGetLastError();
     case MODE_KBUFFER: return launch_kbuffer<false>(f, a, st);
     case MODE_FULL: return launch_full_fwd(f, a, st);
-    case MODE_HIER: return launch_hier_fwd(f, a, st, err);
+    case MODE_HIER: return uses_blend_log(f.s) ? launch_hier_rec(f, a, st, err) : launch_hier_fwd(f, a, st, err);
     default: if (err) *err = "invalid sort mode"; return hipErrorInvalidValue;
     }
 }
@@ -384,7 +387,13 @@ hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, 
         hipLaunchKernelGGL(render_global_bwd_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     case MODE_KBUFFER: return launch_kbuffer<true>(f, a, st);
-    case MODE_HIER: return launch_hier_bwd(f, a, st, err);
+    case MODE_HIER:
+        if (uses_blend_log(f.s)) { // replay the forward's blend log; the resorting kernel only takes overflowed tiles
+            hipError_t e = launch_hier_replay(f, a, st);
+            if (e != hipSuccess) return e;
+            a.flag_mode = 1;
+        }
+        return launch_hier_bwd(f, a, st, err);
     default: if (err) *err = "Backward not supported for full per-pixel sort"; return hipErrorInvalidValue;
     }
 }

@@ -26,7 +26,7 @@ class StpSettings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "sort_mode", "sort_order", "queue_tile_4x4", "queue_tile_2x2", "queue_per_pixel",
         "rect_bounding", "tight_opacity_bounding", "tile_based_culling", "hierarchical_4x4_culling",
-        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1")]
+        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1", "record_blend_log")]
 
 
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
@@ -73,7 +73,7 @@ def _load():
     L.stp_timing_enable.restype = None
     L.stp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.stp_timing_read.restype = ci
-    if L.stp_abi_version() != 1:
+    if L.stp_abi_version() != 2:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L
     return L
@@ -99,6 +99,10 @@ def settings_from_dict(d: dict, tile_rows=None) -> StpSettings:
     tr = tile_rows if tile_rows is not None else d.get("_tile_rows")
     if tr is not None:
         s.tile_y0, s.tile_y1 = int(tr[0]), int(tr[1])
+    # private key set by the autograd function for training forwards (see __init__._RasterizeGaussians.forward);
+    # STP_BACKWARD=resort in the environment forces the reference-style re-sorting backward everywhere
+    if d.get("_record_blend_log") and os.environ.get("STP_BACKWARD", "replay") != "resort":
+        s.record_blend_log = 1
     return s
 
 
@@ -254,7 +258,8 @@ _GEOM_TYPES = {"depths": torch.float32, "clamped": torch.uint8, "radii": torch.i
                "conic_opacity": torch.float32, "rgb": torch.float32, "tiles_touched": torch.int32,
                "point_offsets": torch.int32}
 _BIN_TYPES = {"point_list": torch.int32, "point_list_unsorted": torch.int32, "keys": torch.int64, "keys_unsorted": torch.int64}
-_IMG_TYPES = {"final_T": torch.float32, "n_contrib": torch.int32, "ranges": torch.int32}
+_IMG_TYPES = {"final_T": torch.float32, "n_contrib": torch.int32, "ranges": torch.int32, "tile_flags": torch.int32,
+              "blend_log": torch.int32}  # the last two exist only in a buffer of a recording forward
 
 
 def _view(buf: torch.Tensor, off: int, count: int, dtype) -> torch.Tensor:

@@ -48,10 +48,16 @@ class _RasterizeGaussians(torch.autograd.Function):
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                 raster_settings):
         rs = raster_settings
+        sdict = rs.settings.to_dict()
+        if any(ctx.needs_input_grad):
+            # a backward can follow: let the hierarchical forward record each pixel's blend order so that the
+            # backward replays it instead of re-sorting (extension of ours; ignored by the other sort modes)
+            sdict["_record_blend_log"] = True
+        ctx.settings_dict = sdict
         # positional layout of _C.rasterize_gaussians (22 arguments)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-                rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, rs.settings.to_dict(), rs.render_depth,
+                rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, sdict, rs.render_depth,
                 rs.debug)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)  # snapshot before anything can corrupt them
@@ -79,7 +85,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         # positional layout of _C.rasterize_gaussians_backward (25 arguments)
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
-                rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, rs.settings.to_dict(),
+                rs.sh_degree, rs.campos, geomBuffer, num_rendered, binningBuffer, imgBuffer, ctx.settings_dict,
                 rs.debug)
         if rs.debug:
             cpu_args = cpu_deep_copy_tuple(args)

@@ -42,11 +42,11 @@ class GpuRun:
         from diff_gaussian_rasterization import _C
         self.scene, self.sdict = scene, sdict
         dev = torch.device(device)
-        t = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev).requires_grad_(rg)
+        t = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev).requires_grad_(rg and backward)
         self.means3D, self.opac = t(scene.means3D, True), t(scene.opacities, True)
         self.scales, self.rots = t(scene.scales, True), t(scene.rotations, True)
         self.shs, self.colors = t(scene.shs, True), t(scene.colors_precomp, True)
-        self.means2D = torch.zeros_like(self.means3D, requires_grad=True)
+        self.means2D = torch.zeros_like(self.means3D, requires_grad=backward)
         es = ext_settings(sdict)
         if tile_rows is not None:
             # tile-row window rides along in the dict through a private key (see _C.settings_from_dict)
@@ -65,9 +65,20 @@ class GpuRun:
         self.color = color.detach().cpu().numpy()
         self.radii = radii.cpu().numpy()
         fn = color.grad_fn
-        self.num_rendered = fn.num_rendered
-        saved = fn.saved_tensors
-        self.geom, self.binning, self.img = saved[9], saved[10], saved[11]
+        if fn is not None:
+            self.num_rendered = fn.num_rendered
+            saved = fn.saved_tensors
+            self.geom, self.binning, self.img = saved[9], saved[10], saved[11]
+        else:  # forward-only run (no tensor requires grad): fetch the scratch buffers with a direct _C call
+            empty = torch.Tensor([])
+            e = lambda x: empty if x is None else x
+            out = _C.rasterize_gaussians(rs.bg, self.means3D, e(self.colors), self.opac, self.scales, self.rots, rs.scale_modifier,
+                                         empty, rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy,
+                                         rs.image_height, rs.image_width, e(self.shs), rs.sh_degree, rs.campos, False,
+                                         es.to_dict(), False, debug)
+            self.num_rendered, color2 = out[0], out[1]
+            assert torch.equal(color2, color)
+            self.geom, self.binning, self.img = out[3], out[4], out[5]
         self._C = _C
         self.grads = None
         if backward:
