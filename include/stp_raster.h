@@ -28,7 +28,8 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 2
+#define STP_ABI_VERSION 3
+#define STP_GRAD_RECORD_FLOATS 16 /* floats per Gaussian in grad_records (see stp_backward) */
 
 /* Replaces CudaRasterizer::SplattingSettings + SortSettings + SortQueueSizes + CullingSettings
    (rasterizer.h:27-135) and their json parser (rasterizer.h:160-182): the host binding fills this
@@ -94,7 +95,15 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user,
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:222-257, rasterizer_impl.cu:417-526).
    geom/binning/image buffers are the ones the forward allocated; R is the forward's return value.
-   All dL_d* outputs must be zero-filled by the caller (rasterize_points.cu:178-186). */
+   All outputs and grad_records must be zero-filled by the caller (rasterize_points.cu:178-186).
+
+   grad_records (P x STP_GRAD_RECORD_FLOATS floats) is the hand-over between the two halves of the backward.
+   It takes the place of the reference's dL_dconic scratch tensor (rasterize_points.cu:181): the render half sums
+   its nine per-Gaussian terms into ONE 64-byte record per Gaussian,
+       [0..2] dL/dcolour rgb   [3..4] dL/dmean2D xy   [5..7] dL/dconic xx, xy, yy   [8] dL/dopacity   [9..15] unused
+   (one atomic instruction / one L2 request per flush instead of nine into four arrays: 9x the flush rate on
+   MI355X, tools/global_atomic_bench.hip); the per-Gaussian half reads the record and writes dL_dmean2D,
+   dL_dopacity and dL_dcolor in the reference's layouts along with the remaining gradients. */
 int stp_backward(int P, int D, int M, int R,
                  const float* background, int width, int height,
                  const StpSettings* settings,
@@ -105,16 +114,16 @@ int stp_backward(int P, int D, int M, int R,
                  const float* pixel_colors, const int* radii,
                  char* geom_buffer, char* binning_buffer, char* image_buffer,
                  const float* dL_dpix,
-                 float* dL_dmean2D /* P x 3 */, float* dL_dconic /* P x 4 */, float* dL_dopacity /* P */,
+                 float* dL_dmean2D /* P x 3 */, float* grad_records /* P x 16 */, float* dL_dopacity /* P */,
                  float* dL_dcolor /* P x 3 */, float* dL_dmean3D /* P x 3 */, float* dL_dcov3D /* P x 6 */,
                  float* dL_dsh /* P x M x 3 */, float* dL_dscale /* P x 3 */, float* dL_drot /* P x 4 */,
                  int debug, void* stream);
 
 /* Extension (not in the reference): the two halves of the backward separately, for tile-row sharding.
    phases bit 0 = BACKWARD::render (rasterizer_impl.cu:474-495): accumulates the per-Gaussian partial
-   sums dL_dmean2D / dL_dconic / dL_dopacity / dL_dcolor of THIS rank's tile rows;
-   phases bit 1 = BACKWARD::preprocess (rasterizer_impl.cu:501-525): consumes those four arrays (after the
-   caller has summed them across ranks) and writes the remaining gradients.  phases = 3 == stp_backward. */
+   sums of THIS rank's tile rows into grad_records (nothing else is written);
+   phases bit 1 = BACKWARD::preprocess (rasterizer_impl.cu:501-525): consumes grad_records (after the
+   caller has summed them across ranks) and writes every dL_d* output.  phases = 3 == stp_backward. */
 int stp_backward_phases(int phases, int P, int D, int M, int R,
                         const float* background, int width, int height,
                         const StpSettings* settings,
@@ -125,7 +134,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R,
                         const float* pixel_colors, const int* radii,
                         char* geom_buffer, char* binning_buffer, char* image_buffer,
                         const float* dL_dpix,
-                        float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                        float* dL_dmean2D, float* grad_records, float* dL_dopacity, float* dL_dcolor,
                         float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
                         int debug, void* stream);
 

@@ -365,7 +365,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
                  float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* inv_viewprojmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                  const float* pixel_colors, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
-                 const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 const float* dL_dpix, float* dL_dmean2D, float* grad_records, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -373,9 +373,10 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     if (P == 0) return 0; // reference rasterize_points.cu:191
     if (int rc = check_settings(*settings, true)) return rc;
     if (!geom_buffer || !image_buffer || (R > 0 && !binning_buffer)) return fail(STP_ERR_INVALID_ARGUMENT, "null scratch buffer");
-    if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor) return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
+    if (!grad_records) return fail(STP_ERR_INVALID_ARGUMENT, "null gradient record buffer");
     if ((phases & 1) && (!dL_dpix || !pixel_colors)) return fail(STP_ERR_INVALID_ARGUMENT, "null image gradient");
-    if ((phases & 2) && (!dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot)) return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
+    if ((phases & 2) && (!dL_dmean2D || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot))
+        return fail(STP_ERR_INVALID_ARGUMENT, "null gradient buffer");
 
     FrameParams f;
     fill_frame(f, P, D, M, background, width, height, *settings, means3D, shs, colors_precomp, opacities, scales, scale_modifier,
@@ -387,7 +388,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     if (!radii) radii = g.internal_radii;
 
     BackwardParams bw;
-    bw.pixel_colors = pixel_colors; bw.dL_dpix = dL_dpix; bw.dL_dmean2D = dL_dmean2D; bw.dL_dconic = dL_dconic;
+    bw.pixel_colors = pixel_colors; bw.dL_dpix = dL_dpix; bw.dL_dmean2D = dL_dmean2D; bw.grad_rec = grad_records;
     bw.dL_dopacity = dL_dopacity; bw.dL_dcolor = dL_dcolor; bw.dL_dmean3D = dL_dmean3D; bw.dL_dcov3D = dL_dcov3D; bw.dL_dsh = dL_dsh;
     bw.dL_dscale = dL_dscale; bw.dL_drot = dL_drot;
 
@@ -417,12 +418,12 @@ int stp_backward(int P, int D, int M, int R, const float* background, int width,
                  float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
                  const float* projmatrix, const float* inv_viewprojmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
                  const float* pixel_colors, const int* radii, char* geom_buffer, char* binning_buffer, char* image_buffer,
-                 const float* dL_dpix, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 const float* dL_dpix, float* dL_dmean2D, float* grad_records, float* dL_dopacity, float* dL_dcolor,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug, void* stream)
 {
     return stp_backward_phases(3, P, D, M, R, background, width, height, settings, means3D, shs, opacities, colors_precomp, scales,
                                scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, cam_pos, tan_fovx,
-                               tan_fovy, pixel_colors, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, dL_dconic,
+                               tan_fovy, pixel_colors, radii, geom_buffer, binning_buffer, image_buffer, dL_dpix, dL_dmean2D, grad_records,
                                dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream);
 }
 

@@ -30,10 +30,10 @@ struct BwdPreArgs {
     const float* view;
     const float* proj;
     const float* cam;
-    const float* dL_dmean2D; // P x 3
-    const float* dL_dconic;  // P x 4
-    float* dL_dopacity;
-    const float* dL_dcolor;
+    const float* grad_rec; // P x 16: sums of the render half (layout: stp_raster.h, stp_backward)
+    float* dL_dmean2D;     // P x 3  (out)
+    float* dL_dopacity;    // P      (out)
+    float* dL_dcolor;      // P x 3  (out)
     float* dL_dmean3D;
     float* dL_dcov3D;
     float* dL_dsh;
@@ -49,11 +49,17 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
     const float* __restrict__ proj = a.proj;
     const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
     float3 dmean;
+    // the render half's sums: one 64-byte record, two 16-byte loads and a scalar
+    const float4 rec0 = *reinterpret_cast<const float4*>(a.grad_rec + 16 * (size_t)idx);     // colour r g b, mean2D x
+    const float4 rec1 = *reinterpret_cast<const float4*>(a.grad_rec + 16 * (size_t)idx + 4); // mean2D y, conic xx xy yy
+    const float rec_op = a.grad_rec[16 * (size_t)idx + 8];
+    a.dL_dcolor[3 * (size_t)idx] = rec0.x; a.dL_dcolor[3 * (size_t)idx + 1] = rec0.y; a.dL_dcolor[3 * (size_t)idx + 2] = rec0.z;
+    a.dL_dmean2D[3 * (size_t)idx] = rec0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = rec1.x;
 
     // ---- dL/dconic -> dL/dcov2D -> dL/dcov3D and dL/dmean (covariance path) ----
     {
         const float* cov3D = a.cov3Ds + 6 * (size_t)idx;
-        const float dcx = a.dL_dconic[4 * (size_t)idx], dcy = a.dL_dconic[4 * (size_t)idx + 1], dcz = a.dL_dconic[4 * (size_t)idx + 3];
+        const float dcx = rec1.y, dcy = rec1.z, dcz = rec1.w;
         float3 t;
         t.x = view[0] * mean.x + view[4] * mean.y + view[8] * mean.z + view[12];
         t.y = view[1] * mean.x + view[5] * mean.y + view[9] * mean.z + view[13];
@@ -88,7 +94,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
             // form below is evaluated with the dilated c_xx / c_yy.
             const float det_plus = c_xx * c_yy - c_xy * c_xy;
             const float h_scal = sqrtf(fmaxf(0.000025f, det_cov_orig / det_plus));
-            const float dL_dop_v = a.dL_dopacity[idx];
+            const float dL_dop_v = rec_op;
             const float d_h_scal = dL_dop_v * a.opacities[idx];
             a.dL_dopacity[idx] = dL_dop_v * h_scal;
             const float d_inside_root = (det_cov_orig / det_plus) <= 0.000025f ? 0.f : d_h_scal / (2 * h_scal);
@@ -98,6 +104,8 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
             dL_dc_xx = w * (w * y + y * y + z * z) * denom_f;
             dL_dc_yy = w * (w * x + x * x + z * z) * denom_f;
             dL_dc_xy = -2.f * w * z * (w + x + y) * denom_f;
+        } else {
+            a.dL_dopacity[idx] = rec_op;
         }
         const float denom = c_xx * c_yy - c_xy * c_xy;
         const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
@@ -150,7 +158,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
         const float m_w = 1.0f / (mhw + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
         const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float gx = a.dL_dmean2D[3 * (size_t)idx], gy = a.dL_dmean2D[3 * (size_t)idx + 1];
+        const float gx = rec0.w, gy = rec1.x;
         dmean.x += (proj[0] * m_w - proj[3] * mul1) * gx + (proj[1] * m_w - proj[3] * mul2) * gy;
         dmean.y += (proj[4] * m_w - proj[7] * mul1) * gx + (proj[5] * m_w - proj[7] * mul2) * gy;
         dmean.z += (proj[8] * m_w - proj[11] * mul1) * gx + (proj[9] * m_w - proj[11] * mul2) * gy;
@@ -166,7 +174,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
         float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
         float dRGB[3];
 #pragma unroll
-        for (int ch = 0; ch < 3; ch++) dRGB[ch] = a.dL_dcolor[3 * (size_t)idx + ch] * (a.clamped[3 * (size_t)idx + ch] ? 0.0f : 1.0f);
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = (ch == 0 ? rec0.x : ch == 1 ? rec0.y : rec0.z) * (a.clamped[3 * (size_t)idx + ch] ? 0.0f : 1.0f);
         float ddir[3] = {0, 0, 0};
         const int D = a.D;
 #pragma unroll
@@ -258,7 +266,7 @@ hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState&
     a.means3D = f.means3D; a.radii = radii; a.shs = f.shs; a.clamped = g.clamped; a.opacities = f.opacities; a.scales = f.scales;
     a.rotations = f.rotations; a.cov3Ds = f.cov3D_precomp ? f.cov3D_precomp : g.cov3D; // reference rasterizer_impl.cu:500
     a.view = f.viewmatrix; a.proj = f.projmatrix; a.cam = f.cam_pos;
-    a.dL_dmean2D = bw.dL_dmean2D; a.dL_dconic = bw.dL_dconic; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
+    a.dL_dmean2D = bw.dL_dmean2D; a.grad_rec = bw.grad_rec; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
     a.dL_dmean3D = bw.dL_dmean3D; a.dL_dcov3D = bw.dL_dcov3D; a.dL_dsh = bw.dL_dsh; a.dL_dscale = bw.dL_dscale; a.dL_drot = bw.dL_drot;
     hipLaunchKernelGGL(preprocess_backward_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();

@@ -27,10 +27,7 @@ struct RenderArgs {
     // backward inputs / outputs
     const float* pixel_colors;
     const float* dL_dpix;
-    float* dL_dmean2D; // P x 3
-    float* dL_dconic;  // P x 4
-    float* dL_dopacity;
-    float* dL_dcolor;  // P x 3
+    float* grad_rec;   // P x GRAD_REC floats: the nine sums of a Gaussian in one 64-byte record (stp_raster.h, stp_backward)
     // blend log (training forward -> replay backward): per (tile, wave, k, lane) the list position of the k-th
     // entry that lane's pixel blended; tile_flags[tile] != 0 marks a tile whose log overflowed
     uint32_t* blend_log;
@@ -152,14 +149,13 @@ __device__ __forceinline__ bool blend_backward_terms(BwdPixel& b, const RenderAr
     return true;
 }
 
-// destination of term k of Gaussian id in the reference's gradient tensors
-// (dL_dcolors P x 3, dL_dmeans2D P x 3 [z unused], dL_dconic P x 4 [.z unused], dL_dopacity P)
+// destination of term k of Gaussian id: k = 0..2 dL/dcolour, 3..4 dL/dmean2D, 5..7 dL/dconic (xx, xy, yy),
+// 8 dL/dopacity -- consecutive floats of the Gaussian's 64-byte gradient record, so that nine lanes can hand
+// over all nine sums with ONE atomic instruction that the memory pipeline treats as one request.
+constexpr int GRAD_REC = STP_GRAD_RECORD_FLOATS;
 __device__ __forceinline__ float* grad_slot(const RenderArgs& a, int id, int k)
 {
-    if (k < 3) return &a.dL_dcolor[3 * (size_t)id + k];
-    if (k < 5) return &a.dL_dmean2D[3 * (size_t)id + (k - 3)];
-    if (k < 8) return &a.dL_dconic[4 * (size_t)id + (k == 7 ? 3 : k - 5)];
-    return &a.dL_dopacity[id];
+    return a.grad_rec + (size_t)GRAD_REC * id + k;
 }
 
 // Straightforward accumulation: nine hardware fp32 atomics (global_atomic_add_f32; build with

@@ -110,8 +110,8 @@ struct FrameParams {
 struct BackwardParams {
     const float* pixel_colors;
     const float* dL_dpix;
-    float* dL_dmean2D;
-    float* dL_dconic;
+    float* grad_rec;    // P x 16: written by the render half, read by the per-Gaussian half
+    float* dL_dmean2D;  // outputs of the per-Gaussian half from here on
     float* dL_dopacity;
     float* dL_dcolor;
     float* dL_dmean3D;

@@ -23,6 +23,10 @@ namespace stp {
 
 namespace {
 
+#ifndef STP_REPLAY_ABL
+#define STP_REPLAY_ABL 0 // timing experiments only (1: no eviction atomics, 2: no accumulation at all)
+#endif
+
 constexpr int RW = 128; // cache slots per wave
 
 __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
@@ -37,6 +41,7 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
     __shared__ unsigned long long s_acc[4][9 * RW];
     __shared__ int s_tag[4][RW];
     __shared__ int s_claim[4][RW];
+    __shared__ int s_gid[4][RW]; // Gaussian id of the slot's owner (saves the eviction a dependent point_list load)
 
     const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
     const int s = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
@@ -51,6 +56,7 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
     unsigned long long* const acc = s_acc[w];
     int* const tag = s_tag[w];
     int* const claim = s_claim[w];
+    int* const gid = s_gid[w];
     for (int i = lane; i < RW; i += 64) {
         tag[i] = -1;
 #pragma unroll
@@ -77,35 +83,61 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
     const uint32_t* const log_base = a.blend_log + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane;
     const float pxf = (float)px, pyf = (float)py;
 
-    auto evict = [&](int slot, int old_pos) __attribute__((always_inline)) {
-        const int old_id = (int)a.point_list[range.x + old_pos];
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            const long long v = (long long)acc[k * RW + slot];
-            acc[k * RW + slot] = 0ull;
-            if (v != 0) atomicAdd(grad_slot(a, old_id, k), (float)((double)v * fx_inv));
+    // Hand the sums of up to four slots to memory with ONE atomic instruction: the 16-lane group g takes the
+    // slot its source lane names, lanes 0..8 of the group one of the nine sums each, all going to the same
+    // 64-byte gradient record (one request to the memory pipeline; tools/global_atomic_bench.hip: 9x the rate of
+    // nine single-lane atomics).  `mask` = lanes holding a slot to evict in `slot_v`; wave-uniform control flow.
+    const int grp = lane >> 4, term = lane & 15;
+    auto evict_lanes = [&](unsigned long long mask, int slot_v) __attribute__((always_inline)) {
+        while (mask != 0ull) {
+            // source lane of my group: the grp-th set bit of the mask (scalar bit tricks, then one select chain)
+            const int s0 = __builtin_ctzll(mask);
+            unsigned long long m1 = mask & (mask - 1);
+            const int s1 = m1 ? __builtin_ctzll(m1) : -1;
+            unsigned long long m2 = m1 & (m1 - 1);
+            const int s2 = (m1 && m2) ? __builtin_ctzll(m2) : -1;
+            unsigned long long m3 = m2 & (m2 - 1);
+            const int s3 = (m1 && m2 && m3) ? __builtin_ctzll(m3) : -1;
+            mask = (m1 && m2 && m3) ? (m3 & (m3 - 1)) : 0ull;
+            const int src = grp == 0 ? s0 : grp == 1 ? s1 : grp == 2 ? s2 : s3;
+            const int slot = __shfl(slot_v, src < 0 ? 0 : src);
+            if (src >= 0 && term < 9) {
+                const long long v = (long long)acc[term * RW + slot];
+                if (v != 0) {
+                    acc[term * RW + slot] = 0ull;
+                    atomicAdd(grad_slot(a, gid[slot], term), (float)((double)v * fx_inv));
+                }
+            }
         }
     };
 
-    // one-deep prefetch: (pos, id) of record k are in registers when iteration k starts
-    int pos = (0 < n) ? (int)log_base[0] : -1;
-    int id = (pos >= 0) ? (int)a.point_list[range.x + pos] : 0;
+    // Three dependent loads lead to a blend: log record -> Gaussian id (point_list) -> its data.  They are software
+    // pipelined one step apart, so that an iteration waits for one memory latency, not three: when iteration k
+    // starts, the data of record k, the id of record k+1 and the position of record k+2 are in registers (or in
+    // flight since the previous iteration).
+    auto log_at = [&](int k) __attribute__((always_inline)) { return (k < n) ? (int)log_base[(size_t)k * 64] : -1; };
+    auto id_at = [&](int p) __attribute__((always_inline)) { return (p >= 0) ? (int)a.point_list[range.x + p] : 0; };
+    int pos = log_at(0), pos1 = log_at(1), pos2 = log_at(2);
+    int id = id_at(pos), id1 = id_at(pos1);
+    FrontData fd = load_front(a, id); // (id 0 where there is no record: a harmless read, and no branch around the loads)
     for (int k = 0; k < nmax; k++) {
         const bool have = k < n;
-        FrontData fd{};
-        if (have) fd = load_front(a, id);
+        const FrontData cur_fd = fd;
         const int cur_pos = pos, cur_id = id;
-        if (k + 1 < n) {
-            pos = (int)log_base[(size_t)(k + 1) * 64];
-            id = (int)a.point_list[range.x + pos];
-        }
+        // issue the next round of loads before touching this step's data
+        fd = load_front(a, id1);
+        const int id2 = (k + 2 < n) ? (int)a.point_list[range.x + pos2] : 0;
+        const int pos3 = (k + 3 < n) ? (int)log_base[(size_t)(k + 3) * 64] : -1;
+        pos = pos1; id = id1;
+        pos1 = pos2; id1 = id2;
+        pos2 = pos3;
         float g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         bool ok = false;
         if (have) {
-            const float dx = fd.xy.x - pxf, dy = fd.xy.y - pyf;
-            const float power = -0.5f * (fd.co.x * dx * dx + fd.co.z * dy * dy) - fd.co.y * dx * dy;
+            const float dx = cur_fd.xy.x - pxf, dy = cur_fd.xy.y - pyf;
+            const float power = -0.5f * (cur_fd.co.x * dx * dx + cur_fd.co.z * dy * dy) - cur_fd.co.y * dx * dy;
             const float G = expf(power);
-            ok = blend_backward_terms(bp, a, px, py, fd, G, g);
+            ok = blend_backward_terms(bp, a, px, py, cur_fd, G, g);
             if (!ok) n = k; // (an ulp of difference against the forward's transmittance: stop where it says so)
         }
         // ---- accumulate (converged code: every lane of the wave is here) ----
@@ -140,14 +172,21 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
                 writer = writer && x == 0;
             }
         }
+#if STP_REPLAY_ABL == 2 // (timing experiment)
+        if (g[0] == 123.456f) atomicAdd(grad_slot(a, cur_id, 0), g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] + g[8]);
+        continue;
+#endif
         const int slot = cur_pos & (RW - 1);
         const int owner = writer ? tag[slot] : cur_pos;
         const bool miss = writer && owner != cur_pos;
         if (miss) claim[slot] = lane; // several lanes may want the slot: one wins
         wave_sync();
-        if (miss && claim[slot] == lane) {
-            if (owner >= 0) evict(slot, owner);
+        const bool won = miss && claim[slot] == lane;
+        evict_lanes(__ballot(won && owner >= 0), slot);
+        wave_sync();
+        if (won) {
             tag[slot] = cur_pos;
+            gid[slot] = cur_id;
         }
         wave_sync();
         if (writer) {
@@ -168,9 +207,9 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
         }
     }
     wave_sync();
-    for (int slot = lane; slot < RW; slot += 64) {
-        const int owner = tag[slot];
-        if (owner >= 0) evict(slot, owner);
+    for (int base = 0; base < RW; base += 64) { // final flush: every slot that has an owner
+        const int slot = base + lane;
+        evict_lanes(__ballot(tag[slot] >= 0), slot);
     }
 }
 

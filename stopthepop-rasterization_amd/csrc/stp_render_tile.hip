@@ -214,21 +214,20 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
             const float r0 = wave_sum(g_col[0]), r1 = wave_sum(g_col[1]), r2 = wave_sum(g_col[2]);
             const float r3 = wave_sum(g_mx), r4 = wave_sum(g_my), r5 = wave_sum(g_cxx), r6 = wave_sum(g_cxy), r7 = wave_sum(g_cyy);
             const float r8 = wave_sum(g_op);
-            if (lane < 9) {
-                const int id = s_id[j];
-                float v = r0; float* dst = &a.dL_dcolor[3 * (size_t)id];
+            if (lane < 9) { // lane k hands over term k: nine lanes, one atomic instruction, one 64-byte record
+                float v = r0;
                 switch (lane) {
-                case 1: v = r1; dst = &a.dL_dcolor[3 * (size_t)id + 1]; break;
-                case 2: v = r2; dst = &a.dL_dcolor[3 * (size_t)id + 2]; break;
-                case 3: v = r3; dst = &a.dL_dmean2D[3 * (size_t)id]; break;
-                case 4: v = r4; dst = &a.dL_dmean2D[3 * (size_t)id + 1]; break;
-                case 5: v = r5; dst = &a.dL_dconic[4 * (size_t)id]; break;
-                case 6: v = r6; dst = &a.dL_dconic[4 * (size_t)id + 1]; break;
-                case 7: v = r7; dst = &a.dL_dconic[4 * (size_t)id + 3]; break;
-                case 8: v = r8; dst = &a.dL_dopacity[id]; break;
+                case 1: v = r1; break;
+                case 2: v = r2; break;
+                case 3: v = r3; break;
+                case 4: v = r4; break;
+                case 5: v = r5; break;
+                case 6: v = r6; break;
+                case 7: v = r7; break;
+                case 8: v = r8; break;
                 default: break;
                 }
-                atomicAdd(dst, v);
+                atomicAdd(grad_slot(a, s_id[j], lane), v);
             }
         }
     }
@@ -378,8 +377,7 @@ hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, 
                                   const BackwardParams& bw, hipStream_t st, std::string* err)
 {
     RenderArgs a = make_args(f, g, b, img);
-    a.pixel_colors = bw.pixel_colors; a.dL_dpix = bw.dL_dpix; a.dL_dmean2D = bw.dL_dmean2D; a.dL_dconic = bw.dL_dconic;
-    a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
+    a.pixel_colors = bw.pixel_colors; a.dL_dpix = bw.dL_dpix; a.grad_rec = bw.grad_rec;
     const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(BLOCK);
     if (grid.x == 0) return hipSuccess;
     switch (f.s.sort_mode) {

@@ -21,6 +21,9 @@ _LIB_NAME = "libstp_raster.so"
 _lib = None
 
 
+GRAD_RECORD_FLOATS = 16  # == STP_GRAD_RECORD_FLOATS (include/stp_raster.h): floats per Gaussian in the backward's hand-over buffer
+
+
 class StpSettings(ctypes.Structure):
     """POD mirror of StpSettings (include/stp_raster.h) == reference SplattingSettings (rasterizer.h:129-135)."""
     _fields_ = [(n, ctypes.c_int32) for n in (
@@ -73,7 +76,7 @@ def _load():
     L.stp_timing_enable.restype = None
     L.stp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.stp_timing_read.restype = ci
-    if L.stp_abi_version() != 2:
+    if L.stp_abi_version() != 3:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L
     return L
@@ -198,8 +201,8 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
     Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
 
     Extension for tile-row sharding (not in the reference): phases=1 runs only the render half and
-    returns the four per-Gaussian partial sums (dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors);
-    phases=2 takes those four (after the caller's all-reduce) as `partial` and runs the preprocess half."""
+    returns its per-Gaussian partial sums as the library's (P,16) gradient records (stp_raster.h);
+    phases=2 takes the records (after the caller's all-reduce) as `partial` and runs the preprocess half."""
     L = _load()
     _require_gpu(means3D)
     dev = means3D.device
@@ -207,13 +210,14 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
     M = int(sh.size(1)) if sh.numel() != 0 else 0
     z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-    if partial is not None:
-        dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors = partial
-    else:
-        dL_dmeans2D, dL_dcolors, dL_dconic, dL_dopacity = z(P, 3), z(P, 3), z(P, 2, 2), z(P, 1)
+    records = partial if partial is not None else z(P, GRAD_RECORD_FLOATS)
+    if records.shape != (P, GRAD_RECORD_FLOATS) or records.dtype != torch.float32 or not records.is_contiguous():
+        raise ValueError("partial must be a contiguous float32 (P,%d) tensor" % GRAD_RECORD_FLOATS)
     if phases & 2:
+        dL_dmeans2D, dL_dcolors, dL_dopacity = z(P, 3), z(P, 3), z(P, 1)
         dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 3), z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
     else:
+        dL_dmeans2D = dL_dcolors = dL_dopacity = None
         dL_dmeans3D = dL_dcov3D = dL_dsh = dL_dscales = dL_drotations = None
     s = settings_from_dict(settings_dict)
     if P != 0:
@@ -226,13 +230,13 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
                                        _ptr(sh_), _ptr(op_), _ptr(col_), _ptr(sc_), ctypes.c_float(scale_modifier), _ptr(ro_),
                                        _ptr(c3_), _ptr(vm_), _ptr(pm_), _ptr(inv_), _ptr(cam_), ctypes.c_float(tan_fovx),
                                        ctypes.c_float(tan_fovy), _ptr(pix_), _ptr(radii_), _ptr(geomBuffer),
-                                       _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dl_), _ptr(dL_dmeans2D), _ptr(dL_dconic),
+                                       _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dl_), _ptr(dL_dmeans2D), _ptr(records),
                                        _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
                                        _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)), _stream_ptr(dev))
         if rc < 0:
             _raise_last(rc)
     if phases == 1:
-        return dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors
+        return records
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 
 

@@ -9,8 +9,8 @@ of its rows (StpSettings.tile_y0/tile_y1).  Exchange steps:
              send/recv in RCCL: every peer->root transfer rides its own xGMI link; a ring would be
              bound by one link) -- or all-gathered when every rank needs the frame;
   backward : the render half runs on the rank's rows only and yields PARTIAL per-Gaussian sums
-             (dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor = 11 floats per Gaussian); they are linear
-             inputs of the per-Gaussian backward, so ONE all-reduce(sum) of a packed (P,11) buffer precedes
+             (one 64-byte gradient record per Gaussian, see include/stp_raster.h); they are linear
+             inputs of the per-Gaussian backward, so ONE all-reduce(sum) of the (P,16) record buffer precedes
              the (replicated) preprocess half.  The forward's per-Gaussian state is identical on all ranks
              because visibility is decided on the full frame.
 
@@ -78,16 +78,27 @@ def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, 
 
 
 def pack_partials(dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors) -> torch.Tensor:
-    """(P,3),(P,2,2),(P,1),(P,3) -> one contiguous (P,11) buffer for a single all-reduce."""
+    """The reference's four partial-sum tensors (P,3),(P,2,2),(P,1),(P,3) -> the library's (P,16) gradient records
+    (include/stp_raster.h, stp_backward: colour rgb | mean2D xy | conic xx xy yy | opacity | 7 unused).
+    The product never needs this (the render half of the backward writes records directly and the all-reduce runs
+    on them as they are); it documents the layout and lets CPU tests build records from the oracle's tensors."""
     P = dL_dmeans2D.shape[0]
-    return torch.cat([dL_dmeans2D.reshape(P, 3), dL_dconic.reshape(P, 4), dL_dopacity.reshape(P, 1),
-                      dL_dcolors.reshape(P, 3)], dim=1).contiguous()
+    rec = torch.zeros((P, _C.GRAD_RECORD_FLOATS), dtype=dL_dmeans2D.dtype, device=dL_dmeans2D.device)
+    rec[:, 0:3] = dL_dcolors.reshape(P, 3)
+    rec[:, 3:5] = dL_dmeans2D.reshape(P, 3)[:, 0:2]
+    rec[:, 5:8] = dL_dconic.reshape(P, 4)[:, [0, 1, 3]]
+    rec[:, 8:9] = dL_dopacity.reshape(P, 1)
+    return rec
 
 
-def unpack_partials(buf: torch.Tensor):
-    P = buf.shape[0]
-    return (buf[:, 0:3].contiguous(), buf[:, 3:7].contiguous().reshape(P, 2, 2), buf[:, 7:8].contiguous(),
-            buf[:, 8:11].contiguous())
+def unpack_partials(rec: torch.Tensor):
+    """Inverse of pack_partials: (dL_dmeans2D (P,3), dL_dconic (P,2,2), dL_dopacity (P,1), dL_dcolors (P,3))."""
+    P = rec.shape[0]
+    m2d = torch.zeros((P, 3), dtype=rec.dtype, device=rec.device)
+    m2d[:, 0:2] = rec[:, 3:5]
+    conic = torch.zeros((P, 4), dtype=rec.dtype, device=rec.device)
+    conic[:, [0, 1, 3]] = rec[:, 5:8]
+    return m2d, conic.reshape(P, 2, 2), rec[:, 8:9].contiguous(), rec[:, 0:3].contiguous()
 
 
 class _ShardedRasterize(torch.autograd.Function):
@@ -121,10 +132,9 @@ class _ShardedRasterize(torch.autograd.Function):
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, sdict, rs.debug)
-        partial = _C.rasterize_gaussians_backward(*args, phases=1)
-        buf = pack_partials(*partial)
-        dist.all_reduce(buf)  # sum over ranks: 44 bytes per Gaussian
-        out = _C.rasterize_gaussians_backward(*args, phases=2, partial=unpack_partials(buf))
+        records = _C.rasterize_gaussians_backward(*args, phases=1)
+        dist.all_reduce(records)  # sum over ranks: one 64-byte gradient record per Gaussian
+        out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,

@@ -108,7 +108,7 @@ def test_c_abi_exports_every_declared_symbol():
 
 def test_c_abi_size_and_layout_queries_without_gpu():
     L = _C._load()
-    assert L.stp_abi_version() == 2
+    assert L.stp_abi_version() == 3
     s = _C.settings_from_dict(dgr.ExtendedSettings().to_dict())
     small, big = L.stp_geometry_buffer_size(1000, ctypes.byref(s)), L.stp_geometry_buffer_size(2000, ctypes.byref(s))
     assert 0 < small < big
@@ -150,7 +150,11 @@ def test_strip_pack_assemble_round_trip():
     assert all(s.shape == (3, rows_max * 16, W) for s in strips)
     assert torch.equal(tile_shard.assemble(strips, parts, H), img)
     a, b, c, d = torch.rand(5, 3), torch.rand(5, 2, 2), torch.rand(5, 1), torch.rand(5, 3)
-    ua, ub, uc, ud = tile_shard.unpack_partials(tile_shard.pack_partials(a, b, c, d))
+    a[:, 2] = 0.0   # the gradient records carry what the reference's tensors really use: mean2D x, y ...
+    b[:, 1, 0] = 0  # ... and the three distinct conic terms
+    rec = tile_shard.pack_partials(a, b, c, d)
+    assert rec.shape == (5, 16) and not rec[:, 9:].any()
+    ua, ub, uc, ud = tile_shard.unpack_partials(rec)
     assert torch.equal(ua, a) and torch.equal(ub, b) and torch.equal(uc, c) and torch.equal(ud, d)
 
 
