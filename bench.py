@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--per-step", action="store_true", help="debug: print cumulative wall time after each timed step")
     ap.add_argument("--force-shard", action="store_true", help="use the tile-row sharded path even with one rank (self-test of the exchange code)")
     args = ap.parse_args()
 
@@ -150,9 +151,17 @@ def main():
     barrier()
     _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
     t0 = time.perf_counter()
+    per_step = []
     for _ in range(args.steps):
         step()
+        if args.per_step:  # debug: per-step wall time (adds a sync per step, invalidates the headline number)
+            torch.cuda.synchronize(dev)
+            per_step.append(round(1000.0 * (time.perf_counter() - t0), 3))
     barrier()
+    if args.per_step and rank == 0:
+        print("cumulative ms after each step:", per_step, "reserved GB:", round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+              "num_alloc_retries:", torch.cuda.memory_stats(dev).get("num_alloc_retries"), "segments:",
+              torch.cuda.memory_stats(dev).get("segment.all.allocated"), file=sys.stderr, flush=True)
     dt = time.perf_counter() - t0
     stage_ms = {k: v for k, v in _C.timing_read().items() if v >= 0}  # means over the timed region
     _C.timing_enable(False)

@@ -196,6 +196,43 @@ template <int CAP> struct Window {
         }
         num++;
     }
+    // Branch-free form of insert() for the hot paths: inserts only where `pass` holds.  It reproduces the swap
+    // loop above exactly, ties included: the value carried through the loop is always max(candidate, depth[s-1]),
+    // so slot s swaps iff  d < depth[s]  and not (d < depth[s-1] and depth[s-1] == depth[s]); the payload follows
+    // the same chain, the depths themselves are one median-of-three per slot.
+    __device__ __forceinline__ void insert_if(bool pass, float d, int gid, float st)
+    {
+        const float c = pass ? d : FLT_MAX; // FLT_MAX is smaller than nothing: no slot changes
+        bool sw[CAP];
+        sw[0] = c < depth[0];
+#pragma unroll
+        for (int s = 1; s < CAP; s++) sw[s] = (c < depth[s]) && !((c < depth[s - 1]) && depth[s - 1] == depth[s]);
+#pragma unroll
+        for (int s = 0; s < CAP; s++) {
+            const int oi = id[s];
+            const float os = store[s];
+            id[s] = sw[s] ? gid : oi;
+            store[s] = sw[s] ? st : os;
+            gid = sw[s] ? oi : gid;
+            st = sw[s] ? os : st;
+        }
+#pragma unroll
+        for (int s = CAP - 1; s > 0; s--) depth[s] = __builtin_amdgcn_fmed3f(depth[s - 1], depth[s], c);
+        depth[0] = fminf(depth[0], c);
+        num += (int)pass;
+    }
+    // pop() where `need` holds, as selects
+    __device__ __forceinline__ void pop_if(bool need)
+    {
+#pragma unroll
+        for (int i = 1; i < CAP; i++) {
+            depth[i - 1] = need ? depth[i] : depth[i - 1];
+            store[i - 1] = need ? store[i] : store[i - 1];
+            id[i - 1] = need ? id[i] : id[i - 1];
+        }
+        depth[CAP - 1] = need ? FLT_MAX : depth[CAP - 1];
+        num -= (int)need;
+    }
     __device__ __forceinline__ void pop()
     {
 #pragma unroll

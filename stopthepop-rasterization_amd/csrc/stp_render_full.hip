@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(256) render_full_fwd_kernel(const RenderArgs a
                         const float dx = xy.x - (float)px, dy = xy.y - (float)py;
                         const float power = opacity_factor(dx, dy, co);
                         if (!(power < 0.0f)) {
-                            const float al = fminf(0.99f, co.w * expf(-power));
+                            const float al = fminf(0.99f, co.w * exp_blend(-power));
                             if (!(al < ALPHA_THRESHOLD)) alpha = al;
                         }
                         s_col[0][tid] = a.features[3 * (size_t)id];

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
         if (have) {
             const float dx = cur_fd.xy.x - pxf, dy = cur_fd.xy.y - pyf;
             const float power = -0.5f * (cur_fd.co.x * dx * dx + cur_fd.co.z * dy * dy) - cur_fd.co.y * dx * dy;
-            const float G = expf(power);
+            const float G = exp_blend(power);
             ok = blend_backward_terms(bp, a, px, py, cur_fd, G, g);
             if (!ok) n = k; // (an ulp of difference against the forward's transmittance: stop where it says so)
         }

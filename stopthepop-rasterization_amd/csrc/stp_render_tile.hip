@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
             const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             if (power > 0.0f) continue;
-            const float alpha = fminf(0.99f, co.w * expf(power));
+            const float alpha = fminf(0.99f, co.w * exp_blend(power));
             if (alpha < ALPHA_THRESHOLD) continue;
             const float test_T = T * (1 - alpha);
             if (test_T < T_THRESHOLD) { done = true; continue; }
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
             const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             use = use && !(power > 0.0f);
-            const float G = expf(power);
+            const float G = exp_blend(power);
             const float alpha = fminf(0.99f, co.w * G);
             use = use && !(alpha < ALPHA_THRESHOLD);
             if (!__any(use)) continue;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             const float dx = xy.x - pxf, dy = xy.y - pyf;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             if (power > 0.0f) continue;
-            const float G = expf(power);
+            const float G = exp_blend(power);
             const float alpha = fminf(0.99f, co.w * G);
             if (alpha < ALPHA_THRESHOLD) continue;
             const float depth = depth_along_ray(f4_xyz(s_inv[0][j]), f4_xyz(s_inv[1][j]), f4_xyz(s_inv[2][j]), dir);

@@ -136,19 +136,64 @@ def _stream_ptr(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+# The training forward's image buffer carries the blend log (1 KiB per pixel of the tile grid, 2.1 GB at 1080p).
+# Cycling a block of that size through torch's caching allocator every step invites splitting: smaller requests
+# carve pieces off the free block, the next forward finds no 2 GB hole and the allocator falls back to hipMalloc
+# (tens of ms per step, reserved memory growing by 2 GB a step -- observed on MI355X).  Buffers of this class are
+# therefore kept on a small free list of our own: handed out by the forward, handed back by the backward.
+_BIG_BYTES = 256 << 20
+_BIG_KEEP = 2                # free buffers kept per device
+_big_free = {}               # device index -> [tensor, ...]
+_big_generation = {}         # data_ptr -> how many times the buffer at this address was handed out
+
+
 class _Resizer:
     """The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request."""
 
-    def __init__(self, device):
+    def __init__(self, device, pooled=False):
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.pooled = pooled
         self.cb = _ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, nbytes):
         try:
-            self.tensor.resize_(int(nbytes))
+            nbytes = int(nbytes)
+            if self.pooled and nbytes >= _BIG_BYTES:
+                free = _big_free.setdefault(self.tensor.device.index, [])
+                hit = next((i for i, t in enumerate(free) if t.numel() == nbytes), None)
+                self.tensor = free.pop(hit) if hit is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.tensor.device)
+                ptr = self.tensor.data_ptr()
+                _big_generation[ptr] = _big_generation.get(ptr, 0) + 1
+                return ptr
+            self.tensor.resize_(nbytes)
             return self.tensor.data_ptr() if nbytes else 0
         except Exception:  # surfaces as STP_ERR_ALLOC on the C side
             return 0
+
+
+def scratch_generation(buf: torch.Tensor) -> int:
+    """Token the autograd function keeps with a pooled buffer (0 for ordinary ones); see check_scratch."""
+    return _big_generation.get(buf.data_ptr(), 0) if buf.numel() >= _BIG_BYTES else 0
+
+
+def check_scratch(buf: torch.Tensor, generation: int) -> None:
+    """A second backward through a retained graph after a later forward reused the buffer must not read that
+    forward's blend log: fail loudly instead."""
+    if generation and _big_generation.get(buf.data_ptr(), 0) != generation:
+        raise RuntimeError("the forward's blend log was recycled by a later forward pass; run the forward again "
+                           "before this backward (or set STP_BACKWARD=resort to train without a blend log)")
+
+
+def release_scratch(buf: torch.Tensor) -> None:
+    """Hand a pooled buffer back after the backward that consumed it."""
+    if buf.numel() < _BIG_BYTES or not buf.is_cuda:
+        return
+    free = _big_free.setdefault(buf.device.index, [])
+    if any(t.data_ptr() == buf.data_ptr() for t in free):
+        return
+    free.append(buf)
+    while len(free) > _BIG_KEEP:
+        free.pop(0)
 
 
 def _require_gpu(means3D: torch.Tensor):
@@ -173,7 +218,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev)
+    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev, pooled=True)
     rendered = 0
     if P != 0:
         M = int(sh.size(1)) if sh.numel() != 0 else 0

@@ -72,6 +72,7 @@ class _RasterizeGaussians(torch.autograd.Function):
 
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
+        ctx.img_generation = _C.scratch_generation(imgBuffer)
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, radii
@@ -82,6 +83,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         rs = ctx.raster_settings
         (colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
+        _C.check_scratch(imgBuffer, ctx.img_generation)
         # positional layout of _C.rasterize_gaussians_backward (25 arguments)
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
@@ -99,6 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             out = _C.rasterize_gaussians_backward(*args)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
+        _C.release_scratch(imgBuffer)  # the blend log goes back to the library's free list
         # one gradient per forward input, in forward's order
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)

@@ -116,6 +116,7 @@ class _ShardedRasterize(torch.autograd.Function):
                 rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, sdict, rs.render_depth, rs.debug)
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
         ctx.rs, ctx.sdict, ctx.shard, ctx.num_rendered = rs, sdict, shard, num_rendered
+        ctx.img_generation = _C.scratch_generation(imgBuffer)
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
         full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
@@ -129,12 +130,14 @@ class _ShardedRasterize(torch.autograd.Function):
         dist, rank, world, parts, to_all = ctx.shard
         (colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
+        _C.check_scratch(imgBuffer, ctx.img_generation)
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, sdict, rs.debug)
         records = _C.rasterize_gaussians_backward(*args, phases=1)
         dist.all_reduce(records)  # sum over ranks: one 64-byte gradient record per Gaussian
         out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
+        _C.release_scratch(imgBuffer)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile one bench variant on the GPU box: kernel trace + separate PMC passes, summaries into gpurun_out/<tag>/.
-#   usage: tools/profile.sh <tag> <variant: full|min> [extra bench args]
+#   usage: [PMC_PASSES="1 2"] [STP_RASTER_LIB=...] tools/profile.sh <tag> <variant: full|min> [extra bench args]
 # Raw rocprofv3 output goes to /tmp (it is large); only the per-kernel summaries are kept.
 set -u
 tag=$1; variant=$2; shift 2
@@ -21,6 +21,7 @@ for set in \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum" ; do
   i=$((i+1))
+  case " ${PMC_PASSES:-1 2 3 4 5 6} " in *" $i "*) ;; *) continue;; esac
   rocprofv3 --pmc $set --output-format csv -d /tmp/prof_$tag/pmc$i -- $cmd > "$out/pmc${i}_bench.log" 2>&1
   python $root/profiles/pmc_summary.py /tmp/prof_$tag/pmc$i > "$out/pmc$i.txt" 2>&1
 done
