@@ -57,19 +57,41 @@ def settings_for(variant: str, workload: str):
     return es
 
 
-def algorithmic_bytes(P, P_v, R, N, T, M, S, mode_hier, K, E, sh):
-    """Compulsory HBM traffic per stage, bytes."""
+def algorithmic_bytes(P, P_v, R, N, T, M, S, mode_hier, K, E, sh, B=0):
+    """Compulsory HBM traffic per stage, bytes: every array element the stage must read or
+    write counted once.  P Gaussians, P_v visible, R tile-list entries, N pixels, T tiles, M SH coefficients,
+    S = 1 if the mode needs Sigma^-1, K/E = per-tile-depth / culling extras of duplicate, B = blended
+    (pixel, entry) pairs recorded in the blend log (hierarchical training forward; 0 otherwise)."""
     b = {}
     b["preprocess"] = P * (44 + 8) + P_v * (12 * M * sh + 60 + 48 * S + 15 * sh)
     b["scan"] = 8 * P
     b["duplicate"] = 8 * P + P_v * (20 + 16 * E + 48 * K) + 12 * R
     b["sort"] = 24 * R
     b["ranges"] = 8 * R + 16 * T
-    b["render_fwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (0 if mode_hier else 4))
-    b["zero_fill"] = P * (108 + 12 * M)
-    b["render_bwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (12 if S else 4)) + 88 * P_v
-    b["bwd_preprocess"] = 4 * P + P_v * (52 + 36) + 4 * P + P_v * (36 + sh * (12 * M + 15) + 52) + P_v * (12 + sh * 12 * M + 28)
+    # forward render: every list entry's id + conic/opacity + mean + Sigma^-1 pack + colour once per tile, the pixel outputs,
+    # and (recording forward) the 4-byte log record of every blended pair + n_contrib + tile flags
+    b["render_fwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (0 if mode_hier else 4)) + (4 * B + 4 * N + 4 * T if B else 0)
+    b["zero_fill"] = P * (64 + 44 + 12 * M + 64)
+    if B:   # replay backward: the log, the per-entry data that is blended (id, conic/opacity, mean, colour), the pixel state,
+            # and one read-modify-write of every visible Gaussian's 64-byte gradient record
+        b["render_bwd"] = 8 * T + 4 * B + R * (4 + 24 + 12) + N * (4 + 4 + 12 + 12) + 128 * P_v
+    else:
+        b["render_bwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (12 if S else 4)) + 128 * P_v
+    b["bwd_preprocess"] = 4 * P + P_v * (64 + 36) + 4 * P + P_v * (36 + sh * (12 * M + 15) + 52) + P_v * (12 + sh * 12 * M + 28 + 28)
     return b
+
+
+def measured_traffic(kernel: str, workload: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/profile.sh + tools/traffic_json.py on the GPU box: FETCH_SIZE and WRITE_SIZE collected in separate passes,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this kernel exists."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(workload, {}).get(kernel)
+        return int(e["hbm_bytes_per_launch"]) if e else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def main():
@@ -189,11 +211,26 @@ def main():
         S = 1 if (mode != 0 or order >= 2) else 0
         Kf = 1 if order >= 2 else 0
         E = 1 if (sdict["culling_settings"]["tile_based_culling"] or order == 3) else 0
-        bts = algorithmic_bytes(P, P_v, R, N, T, 16, S, mode == 3, Kf, E, 1)
+        # blended pairs recorded by the training forward (one untimed forward; the timed graphs are gone)
+        B = 0
+        head, mid = int(sdict["sort_settings"]["queue_sizes"]["per_pixel"]), int(sdict["sort_settings"]["queue_sizes"]["tile_2x2"])
+        cull = bool(sdict["culling_settings"]["hierarchical_4x4_culling"])
+        recording = mode == 3 and not fwd_only and os.environ.get("STP_BACKWARD", "replay") != "resort" and not sharded
+        if recording:
+            c2, _ = raster(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+            B = int(_C.image_array(c2.grad_fn.saved_tensors[11], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256).sum().item())
+            del c2
+        bts = algorithmic_bytes(P, P_v, R, N, T, 16, S, mode == 3, Kf, E, 1, B)
         dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
         dom_bytes = bts["render_bwd"] if dom == "BwdRender" else bts["render_fwd"]
         dom_ms = stage_ms.get(dom, float("nan"))
         achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
+        if mode == 3:
+            kname = ("render_hier_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1>") if dom == "BwdRender" \
+                else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}>"
+        else:
+            kname = {0: "render_global", 1: "render_full", 2: "render_kbuffer"}[mode] + ("_backward_kernel" if dom == "BwdRender" else "_forward_kernel")
+        traffic = measured_traffic(kname, f"{args.workload}-{args.variant}")
         fwd_bytes = sum(bts[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"))
         bwd_bytes = sum(bts[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess"))
         out = {
@@ -204,14 +241,14 @@ def main():
             "config": {"workload": f"{args.workload}-{args.variant}: {P} Gaussians, {scene.W}x{scene.H}, SH degree 3, "
                                    f"sort_mode={mode} sort_order={order} culling={sdict['culling_settings']} "
                                    f"{'fwd' if fwd_only else 'fwd+bwd'}",
-                       "P": P, "P_visible": P_v, "num_rendered": R, "tiles": T,
+                       "P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B,
                        "parallelism": (f"tilerows{world}" if sharded else f"frames{world}") if world > 1 else "single",
                        "scale": args.scale},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": {"forward": int(fwd_bytes), "backward": int(bwd_bytes)},
-            "roofline": {"bound": "hbm", "kernel": "render_hier_kernel" + ("<backward>" if dom == "BwdRender" else "<forward>"),
+            "roofline": {"bound": "hbm", "kernel": kname,
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(((fwd_bytes + (0 if fwd_only else bwd_bytes)) / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)},
         }
