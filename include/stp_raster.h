@@ -95,7 +95,9 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user,
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:222-257, rasterizer_impl.cu:417-526).
    geom/binning/image buffers are the ones the forward allocated; R is the forward's return value.
-   All outputs and grad_records must be zero-filled by the caller (rasterize_points.cu:178-186).
+   grad_records must be zero-filled by the caller.  The dL_d* outputs need not be (the reference zero-fills them,
+   rasterize_points.cu:178-186): every row of every output is written, zeros for Gaussians outside the frustum --
+   except dL_dscale / dL_drot when cov3D_precomp is given (then they are left untouched, as in the reference).
 
    grad_records (P x STP_GRAD_RECORD_FLOATS floats) is the hand-over between the two halves of the backward.
    It takes the place of the reference's dL_dconic scratch tensor (rasterize_points.cu:181): the render half sums

@@ -41,10 +41,10 @@ struct BwdPreArgs {
     float* dL_drot;
 };
 
-__global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreArgs a)
+// Everything for one visible Gaussian.  sh_row / dsh_row: this Gaussian's 3M SH coefficients and their gradient,
+// both in the SAME LDS row (the kernel stages them, see below): each channel reads what it needs before it writes.
+__device__ __forceinline__ void gaussian_backward(const BwdPreArgs& a, int idx, float* sh_row)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.P || !(a.radii[idx] > 0)) return;
     const float* __restrict__ view = a.view;
     const float* __restrict__ proj = a.proj;
     const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
@@ -170,8 +170,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
         const float3 v = make_float3(mean.x - cam.x, mean.y - cam.y, mean.z - cam.z);
         const float len = sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
         const float x = v.x / len, y = v.y / len, z = v.z / len;
-        const float* sh = a.shs + (size_t)idx * a.M * 3;
-        float* dsh = a.dL_dsh + (size_t)idx * a.M * 3;
+        float* const dsh = sh_row; // in place: gradient row over coefficient row
         float dRGB[3];
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) dRGB[ch] = (ch == 0 ? rec0.x : ch == 1 ? rec0.y : rec0.z) * (a.clamped[3 * (size_t)idx + ch] ? 0.0f : 1.0f);
@@ -181,30 +180,35 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
         for (int ch = 0; ch < 3; ch++) {
             float dx = 0, dy = 0, dz = 0;
             const float g = dRGB[ch];
+            // the coefficients this channel's direction derivative needs, read before their slots are overwritten
+            float sh[16];
+#pragma unroll
+            for (int k = 1; k < 16; k++) sh[k] = (k < a.M && k < (D + 1) * (D + 1)) ? sh_row[3 * k + ch] : 0.0f;
+            for (int k = (D + 1) * (D + 1); k < a.M; k++) dsh[3 * k + ch] = 0.0f; // coefficients above the active degree
             dsh[ch] = kSH_C0 * g;
             if (D > 0) {
                 dsh[3 + ch] = (-kSH_C1 * y) * g; dsh[6 + ch] = (kSH_C1 * z) * g; dsh[9 + ch] = (-kSH_C1 * x) * g;
-                dx = -kSH_C1 * sh[9 + ch]; dy = -kSH_C1 * sh[3 + ch]; dz = kSH_C1 * sh[6 + ch];
+                dx = -kSH_C1 * sh[3]; dy = -kSH_C1 * sh[1]; dz = kSH_C1 * sh[2];
                 if (D > 1) {
                     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                     dsh[12 + ch] = (kSH_C2[0] * xy) * g; dsh[15 + ch] = (kSH_C2[1] * yz) * g; dsh[18 + ch] = (kSH_C2[2] * (2.f * zz - xx - yy)) * g;
                     dsh[21 + ch] = (kSH_C2[3] * xz) * g; dsh[24 + ch] = (kSH_C2[4] * (xx - yy)) * g;
-                    dx += kSH_C2[0] * y * sh[12 + ch] + kSH_C2[2] * 2.f * -x * sh[18 + ch] + kSH_C2[3] * z * sh[21 + ch] + kSH_C2[4] * 2.f * x * sh[24 + ch];
-                    dy += kSH_C2[0] * x * sh[12 + ch] + kSH_C2[1] * z * sh[15 + ch] + kSH_C2[2] * 2.f * -y * sh[18 + ch] + kSH_C2[4] * 2.f * -y * sh[24 + ch];
-                    dz += kSH_C2[1] * y * sh[15 + ch] + kSH_C2[2] * 2.f * 2.f * z * sh[18 + ch] + kSH_C2[3] * x * sh[21 + ch];
+                    dx += kSH_C2[0] * y * sh[4] + kSH_C2[2] * 2.f * -x * sh[6] + kSH_C2[3] * z * sh[7] + kSH_C2[4] * 2.f * x * sh[8];
+                    dy += kSH_C2[0] * x * sh[4] + kSH_C2[1] * z * sh[5] + kSH_C2[2] * 2.f * -y * sh[6] + kSH_C2[4] * 2.f * -y * sh[8];
+                    dz += kSH_C2[1] * y * sh[5] + kSH_C2[2] * 2.f * 2.f * z * sh[6] + kSH_C2[3] * x * sh[7];
                     if (D > 2) {
                         dsh[27 + ch] = (kSH_C3[0] * y * (3.f * xx - yy)) * g; dsh[30 + ch] = (kSH_C3[1] * xy * z) * g;
                         dsh[33 + ch] = (kSH_C3[2] * y * (4.f * zz - xx - yy)) * g; dsh[36 + ch] = (kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * g;
                         dsh[39 + ch] = (kSH_C3[4] * x * (4.f * zz - xx - yy)) * g; dsh[42 + ch] = (kSH_C3[5] * z * (xx - yy)) * g;
                         dsh[45 + ch] = (kSH_C3[6] * x * (xx - 3.f * yy)) * g;
-                        dx += (kSH_C3[0] * sh[27 + ch] * 3.f * 2.f * xy + kSH_C3[1] * sh[30 + ch] * yz + kSH_C3[2] * sh[33 + ch] * -2.f * xy +
-                               kSH_C3[3] * sh[36 + ch] * -3.f * 2.f * xz + kSH_C3[4] * sh[39 + ch] * (-3.f * xx + 4.f * zz - yy) +
-                               kSH_C3[5] * sh[42 + ch] * 2.f * xz + kSH_C3[6] * sh[45 + ch] * 3.f * (xx - yy));
-                        dy += (kSH_C3[0] * sh[27 + ch] * 3.f * (xx - yy) + kSH_C3[1] * sh[30 + ch] * xz + kSH_C3[2] * sh[33 + ch] * (-3.f * yy + 4.f * zz - xx) +
-                               kSH_C3[3] * sh[36 + ch] * -3.f * 2.f * yz + kSH_C3[4] * sh[39 + ch] * -2.f * xy + kSH_C3[5] * sh[42 + ch] * -2.f * yz +
-                               kSH_C3[6] * sh[45 + ch] * -3.f * 2.f * xy);
-                        dz += (kSH_C3[1] * sh[30 + ch] * xy + kSH_C3[2] * sh[33 + ch] * 4.f * 2.f * yz + kSH_C3[3] * sh[36 + ch] * 3.f * (2.f * zz - xx - yy) +
-                               kSH_C3[4] * sh[39 + ch] * 4.f * 2.f * xz + kSH_C3[5] * sh[42 + ch] * (xx - yy));
+                        dx += (kSH_C3[0] * sh[9] * 3.f * 2.f * xy + kSH_C3[1] * sh[10] * yz + kSH_C3[2] * sh[11] * -2.f * xy +
+                               kSH_C3[3] * sh[12] * -3.f * 2.f * xz + kSH_C3[4] * sh[13] * (-3.f * xx + 4.f * zz - yy) +
+                               kSH_C3[5] * sh[14] * 2.f * xz + kSH_C3[6] * sh[15] * 3.f * (xx - yy));
+                        dy += (kSH_C3[0] * sh[9] * 3.f * (xx - yy) + kSH_C3[1] * sh[10] * xz + kSH_C3[2] * sh[11] * (-3.f * yy + 4.f * zz - xx) +
+                               kSH_C3[3] * sh[12] * -3.f * 2.f * yz + kSH_C3[4] * sh[13] * -2.f * xy + kSH_C3[5] * sh[14] * -2.f * yz +
+                               kSH_C3[6] * sh[15] * -3.f * 2.f * xy);
+                        dz += (kSH_C3[1] * sh[10] * xy + kSH_C3[2] * sh[11] * 4.f * 2.f * yz + kSH_C3[3] * sh[12] * 3.f * (2.f * zz - xx - yy) +
+                               kSH_C3[4] * sh[13] * 4.f * 2.f * xz + kSH_C3[5] * sh[14] * (xx - yy));
                     }
                 }
             }
@@ -256,6 +260,78 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
     }
 }
 
+// One workgroup = 256 consecutive Gaussians.  Their SH coefficients (3M floats each, 192 B at degree 3) and the SH
+// gradients are the bulk of this kernel's traffic, and a thread-per-Gaussian access to them is a 192-byte-stride
+// gather/scatter (measured: 4x the compulsory HBM traffic).  The block therefore moves both through LDS: coalesced
+// 16-byte loads of the whole 256 x 3M block, rows padded to 3M+1 words (conflict-free row access), the gradient
+// written over the coefficients in place, coalesced stores back.  Every output row of every Gaussian is written
+// (zeros for the invisible ones), so none of the dL_d* outputs needs a zero-fill by the caller.
+__global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreArgs a)
+{
+    extern __shared__ float s_rows[]; // [256][3M + 1]
+    const int tid = (int)threadIdx.x;
+    const int base = (int)blockIdx.x * 256;
+    const int idx = base + tid;
+    const int rows = min(256, a.P - base);
+    const int row_len = 3 * a.M, row_stride = row_len + 1;
+    const bool have_sh = a.shs != nullptr && a.M > 0;
+    if (have_sh) {
+        const float* __restrict__ src = a.shs + (size_t)base * row_len;
+        const int total = rows * row_len;
+        if ((row_len & 3) == 0) {
+            for (int f = 4 * tid; f < total; f += 4 * 256) {
+                const float4 v = *reinterpret_cast<const float4*>(src + f);
+                const int r = f / row_len, j = f - r * row_len;
+                float* d = s_rows + r * row_stride + j;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int f = tid; f < total; f += 256) {
+                const int r = f / row_len, j = f - r * row_len;
+                s_rows[r * row_stride + j] = src[f];
+            }
+        }
+        __syncthreads();
+    }
+    if (idx < a.P) {
+        if (a.radii[idx] > 0) {
+            gaussian_backward(a, idx, s_rows + tid * row_stride);
+        } else { // invisible: all gradients are zero
+            a.dL_dcolor[3 * (size_t)idx] = 0.0f; a.dL_dcolor[3 * (size_t)idx + 1] = 0.0f; a.dL_dcolor[3 * (size_t)idx + 2] = 0.0f;
+            a.dL_dmean2D[3 * (size_t)idx] = 0.0f; a.dL_dmean2D[3 * (size_t)idx + 1] = 0.0f;
+            a.dL_dopacity[idx] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.0f;
+            if (a.scales != nullptr) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) a.dL_dscale[3 * (size_t)idx + i] = 0.0f;
+                reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (have_sh) for (int j = 0; j < row_len; j++) s_rows[tid * row_stride + j] = 0.0f;
+        }
+        a.dL_dmean2D[3 * (size_t)idx + 2] = 0.0f; // z component: never used by the reference either
+    }
+    if (have_sh) {
+        __syncthreads();
+        float* __restrict__ dst = a.dL_dsh + (size_t)base * row_len;
+        const int total = rows * row_len;
+        if ((row_len & 3) == 0) {
+            for (int f = 4 * tid; f < total; f += 4 * 256) {
+                const int r = f / row_len, j = f - r * row_len;
+                const float* d = s_rows + r * row_stride + j;
+                *reinterpret_cast<float4*>(dst + f) = make_float4(d[0], d[1], d[2], d[3]);
+            }
+        } else {
+            for (int f = tid; f < total; f += 256) {
+                const int r = f / row_len, j = f - r * row_len;
+                dst[f] = s_rows[r * row_stride + j];
+            }
+        }
+    }
+}
+
 } // namespace
 
 hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState& g, const int* radii, const BackwardParams& bw, hipStream_t st)
@@ -268,7 +344,12 @@ hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState&
     a.view = f.viewmatrix; a.proj = f.projmatrix; a.cam = f.cam_pos;
     a.dL_dmean2D = bw.dL_dmean2D; a.grad_rec = bw.grad_rec; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
     a.dL_dmean3D = bw.dL_dmean3D; a.dL_dcov3D = bw.dL_dcov3D; a.dL_dsh = bw.dL_dsh; a.dL_dscale = bw.dL_dscale; a.dL_drot = bw.dL_drot;
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
+    const size_t lds = (a.shs != nullptr && a.M > 0) ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
+    if (lds > 64 * 1024) { // above the default dynamic-LDS limit (M > 21: no SH degree the reference knows)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((f.P + 255) / 256), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

@@ -259,8 +259,12 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
     if records.shape != (P, GRAD_RECORD_FLOATS) or records.dtype != torch.float32 or not records.is_contiguous():
         raise ValueError("partial must be a contiguous float32 (P,%d) tensor" % GRAD_RECORD_FLOATS)
     if phases & 2:
-        dL_dmeans2D, dL_dcolors, dL_dopacity = z(P, 3), z(P, 3), z(P, 1)
-        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = z(P, 3), z(P, 6), z(P, M, 3), z(P, 3), z(P, 4)
+        # the per-Gaussian half writes every row of its outputs (zeros for invisible Gaussians): no zero-fill needed,
+        # except for the scale/rotation gradients when a precomputed covariance is used (then they are not touched)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        zs = e if scales.numel() != 0 else z
+        dL_dmeans2D, dL_dcolors, dL_dopacity = e(P, 3), e(P, 3), e(P, 1)
+        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 3), e(P, 6), e(P, M, 3), zs(P, 3), zs(P, 4)
     else:
         dL_dmeans2D = dL_dcolors = dL_dopacity = None
         dL_dmeans3D = dL_dcov3D = dL_dsh = dL_dscales = dL_drotations = None
