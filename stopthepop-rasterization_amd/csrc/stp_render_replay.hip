@@ -21,13 +21,28 @@
 
 namespace stp {
 
+#ifdef STP_REPLAY_STATS
+__device__ unsigned long long g_replay_stats[16];
+#endif
+
 namespace {
 
 #ifndef STP_REPLAY_ABL
 #define STP_REPLAY_ABL 0 // timing experiments only (1: no eviction atomics, 2: no accumulation at all)
 #endif
 
-constexpr int RW = 128; // cache slots per wave
+#ifndef STP_REPLAY_PREREDUCE
+#define STP_REPLAY_PREREDUCE 1 // DPP pre-reduction of quads / sub-tiles on one position: measured on C2, same-position lanes are
+                                // spread over the wave (55 blending lanes, 17.5 positions, 41.7 after a perfect per-quad merge): not worth its 50 instructions
+#endif
+
+#ifndef STP_REPLAY_RW
+#define STP_REPLAY_RW 112 // 112 slots x 72 B x 4 waves + tags = 38 KB: four workgroups per CU (128 slots: three); measured best on C2
+#endif
+#ifndef STP_REPLAY_OCC
+#define STP_REPLAY_OCC 4
+#endif
+constexpr int RW = STP_REPLAY_RW; // cache slots per wave
 
 __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
 {
@@ -36,7 +51,7 @@ __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-__global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const RenderArgs a)
+__global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel(const RenderArgs a)
 {
     __shared__ unsigned long long s_acc[4][9 * RW];
     __shared__ int s_tag[4][RW];
@@ -146,6 +161,7 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
         // so that one lane goes to LDS instead of 4 (16) lanes hitting the same address.
         const int key = ok ? cur_pos : -2 - lane; // unique when not blending
         bool writer = ok;
+#if STP_REPLAY_PREREDUCE
         {
             const int k0 = quad_bcast_i<0>(key), k1 = quad_bcast_i<1>(key), k2 = quad_bcast_i<2>(key), k3 = quad_bcast_i<3>(key);
             const bool quad_same = (k0 == k1) && (k0 == k2) && (k0 == k3);
@@ -176,12 +192,41 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
         if (g[0] == 123.456f) atomicAdd(grad_slot(a, cur_id, 0), g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] + g[8]);
         continue;
 #endif
-        const int slot = cur_pos & (RW - 1);
+#endif
+#ifdef STP_REPLAY_STATS
+        {   // per wave-step: blending lanes, writer lanes after the pre-reductions, distinct positions among writers / blenders
+            int first_w = writer ? 1 : 0, first_b = ok ? 1 : 0, first_q = ok ? 1 : 0, first_r = ok ? 1 : 0;
+            for (int j = 0; j < 64; j++) {
+                const int kj = __shfl(key, j);
+                const int wj = __shfl((int)writer, j);
+                const int oj = __shfl((int)ok, j);
+                if (j < lane && kj == key) {
+                    if (wj) first_w = 0;
+                    if (oj) first_b = 0;
+                    if (oj && (j >> 2) == (lane >> 2)) first_q = 0;
+                    if (oj && (j >> 4) == (lane >> 4)) first_r = 0;
+                }
+            }
+            const int dq = __popcll(__ballot(ok && first_q)), dr = __popcll(__ballot(ok && first_r));
+            if (lane == 0) { atomicAdd(&g_replay_stats[5], (unsigned long long)dq); atomicAdd(&g_replay_stats[6], (unsigned long long)dr); }
+            const int nb = __popcll(__ballot(ok)), nw = __popcll(__ballot(writer));
+            const int dw = __popcll(__ballot(writer && first_w)), db = __popcll(__ballot(ok && first_b));
+            if (lane == 0) {
+                atomicAdd(&g_replay_stats[0], 1ull); atomicAdd(&g_replay_stats[1], (unsigned long long)nb);
+                atomicAdd(&g_replay_stats[2], (unsigned long long)nw); atomicAdd(&g_replay_stats[3], (unsigned long long)dw);
+                atomicAdd(&g_replay_stats[4], (unsigned long long)db);
+            }
+        }
+#endif
+        const int slot = (RW & (RW - 1)) == 0 ? (cur_pos & (RW - 1)) : (int)((unsigned)cur_pos % (unsigned)RW); // (cur_pos >= 0 for every lane that uses it)
         const int owner = writer ? tag[slot] : cur_pos;
         const bool miss = writer && owner != cur_pos;
         if (miss) claim[slot] = lane; // several lanes may want the slot: one wins
         wave_sync();
         const bool won = miss && claim[slot] == lane;
+#ifdef STP_REPLAY_STATS
+        { const int ne = __popcll(__ballot(won && owner >= 0)), nm = __popcll(__ballot(miss)); if (lane == 0) { atomicAdd(&g_replay_stats[7], (unsigned long long)ne); atomicAdd(&g_replay_stats[8], (unsigned long long)nm); } }
+#endif
         evict_lanes(__ballot(won && owner >= 0), slot);
         wave_sync();
         if (won) {
@@ -201,6 +246,9 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
                     atomicAdd(&acc[kk * RW + slot], (unsigned long long)qv);
                 }
             } else { // lost the slot to another position in this very step, or a term too large for the fixed point
+#ifdef STP_REPLAY_STATS
+                atomicAdd(&g_replay_stats[9], 1ull);
+#endif
 #pragma unroll
                 for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
             }
@@ -209,11 +257,21 @@ __global__ void __launch_bounds__(256, 3) render_hier_replay_kernel(const Render
     wave_sync();
     for (int base = 0; base < RW; base += 64) { // final flush: every slot that has an owner
         const int slot = base + lane;
-        evict_lanes(__ballot(tag[slot] >= 0), slot);
+        evict_lanes(__ballot(slot < RW && tag[min(slot, RW - 1)] >= 0), slot);
     }
 }
 
 } // namespace
+
+#ifdef STP_REPLAY_STATS
+extern "C" int stp_debug_replay_stats(unsigned long long* out16)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_replay_stats), sizeof(unsigned long long) * 16);
+    unsigned long long z[16] = {};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_replay_stats), z, sizeof(z));
+    return (int)e;
+}
+#endif
 
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {

@@ -77,6 +77,9 @@ def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, 
     return assemble(bufs, parts, H) if rank == dst else None
 
 
+RECORD_USED = 9  # floats of a gradient record that carry data (include/stp_raster.h, stp_backward)
+
+
 def pack_partials(dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors) -> torch.Tensor:
     """The reference's four partial-sum tensors (P,3),(P,2,2),(P,1),(P,3) -> the library's (P,16) gradient records
     (include/stp_raster.h, stp_backward: colour rgb | mean2D xy | conic xx xy yy | opacity | 7 unused).
@@ -135,7 +138,11 @@ class _ShardedRasterize(torch.autograd.Function):
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, sdict, rs.debug)
         records = _C.rasterize_gaussians_backward(*args, phases=1)
-        dist.all_reduce(records)  # sum over ranks: one 64-byte gradient record per Gaussian
+        # sum over ranks.  Only 9 of a record's 16 floats carry data (the padding buys single-request atomics on
+        # chip, it should not cross xGMI): 36 instead of 64 bytes per Gaussian on the wire.
+        used = records[:, :RECORD_USED].contiguous()
+        dist.all_reduce(used)
+        records[:, :RECORD_USED] = used
         out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
         _C.release_scratch(imgBuffer)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,

@@ -155,6 +155,18 @@ def test_debug_flag_synchronises_and_gives_the_same_frame():
     assert np.array_equal(a.color, b.color)
 
 
+@pytest.mark.parametrize("degree,M", [(0, 16), (1, 16), (2, 9), (1, 4), (0, 1)])
+def test_sh_degrees_and_coefficient_counts(degree, M):
+    """Active SH degree below the stored one, and SH tensors with fewer coefficients (row lengths 48, 27, 12, 3
+    floats: both the 16-byte and the scalar staging path of the per-Gaussian backward)."""
+    sc = scenes.make_scene(P=700, W=64, H=48, sigma_min=2.0, sigma_max=9.0, seed=31, camera="orbit")
+    sc.shs = np.ascontiguousarray(sc.shs[:, :M, :])
+    sc.sh_degree = degree
+    g, f = check_against_oracle(sc, settings_dict(3, h44=True))
+    assert g.grads["dL_dsh"].shape == (700, M, 3)
+    assert not np.any(g.grads["dL_dsh"][:, (degree + 1) ** 2:, :])  # nothing flows into inactive coefficients
+
+
 # ---- blend log (training forward records the blend order, backward replays it) ----
 HAZE = dict(P=3000, W=48, H=48, sigma_min=10.0, sigma_max=20.0, seed=21, opacity_range=(0.01, 0.03))
 
