@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--train-forward-only", action="store_true",
+                    help="debug: forward passes that expect a backward (recording forward) without running it; read stage_ms only")
     ap.add_argument("--per-step", action="store_true", help="debug: print cumulative wall time after each timed step")
     ap.add_argument("--force-shard", action="store_true", help="use the tile-row sharded path even with one rank (self-test of the exchange code)")
     args = ap.parse_args()
@@ -160,8 +162,10 @@ def main():
                 x.grad = None
         color, radii = raster(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
         state["color"], state["radii"] = color, radii
-        if not fwd_only:
+        if not fwd_only and not args.train_forward_only:
             (color * w_img).sum().backward()
+        elif args.train_forward_only:
+            _C.release_scratch(color.grad_fn.saved_tensors[11])  # nobody will replay this log: hand the buffer back
 
     def barrier():
         if dist is not None:
@@ -215,7 +219,7 @@ def main():
         B = 0
         head, mid = int(sdict["sort_settings"]["queue_sizes"]["per_pixel"]), int(sdict["sort_settings"]["queue_sizes"]["tile_2x2"])
         cull = bool(sdict["culling_settings"]["hierarchical_4x4_culling"])
-        recording = mode == 3 and not fwd_only and os.environ.get("STP_BACKWARD", "replay") != "resort" and not sharded
+        recording = mode in (2, 3) and not fwd_only and os.environ.get("STP_BACKWARD", "replay") != "resort" and not sharded
         if recording:
             c2, _ = raster(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
             B = int(_C.image_array(c2.grad_fn.saved_tensors[11], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256).sum().item())
@@ -229,7 +233,10 @@ def main():
             kname = ("render_hier_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1>") if dom == "BwdRender" \
                 else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}>"
         else:
-            kname = {0: "render_global", 1: "render_full", 2: "render_kbuffer"}[mode] + ("_backward_kernel" if dom == "BwdRender" else "_forward_kernel")
+            kname = {0: "render_global", 1: "render_full", 2: "render_kbuffer"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
+            if mode == 2:
+                kname = "render_hier_replay_kernel" if (dom == "BwdRender" and recording) else \
+                    f"render_kbuffer_kernel<{head}, {1 if dom == 'BwdRender' else (2 if recording else 0)}>"
         traffic = measured_traffic(kname, f"{args.workload}-{args.variant}")
         fwd_bytes = sum(bts[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"))
         bwd_bytes = sum(bts[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess"))

@@ -206,7 +206,8 @@ template <int CAP> struct Window {
         bool sw[CAP];
         sw[0] = c < depth[0];
 #pragma unroll
-        for (int s = 1; s < CAP; s++) sw[s] = (c < depth[s]) && !((c < depth[s - 1]) && depth[s - 1] == depth[s]);
+        for (int s = 1; s < CAP; s++) // (bitwise operators: no short-circuit control flow)
+            sw[s] = (bool)((int)(c < depth[s]) & ~((int)(c < depth[s - 1]) & (int)(depth[s - 1] == depth[s])) & 1);
 #pragma unroll
         for (int s = 0; s < CAP; s++) {
             const int oi = id[s];

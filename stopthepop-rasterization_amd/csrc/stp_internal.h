@@ -17,7 +17,7 @@ constexpr size_t ALIGN = 256; // sub-array alignment inside the scratch buffers
 enum SortMode { MODE_GLOBAL = 0, MODE_FULL = 1, MODE_KBUFFER = 2, MODE_HIER = 3 };
 enum SortOrder { ORDER_Z = 0, ORDER_DISTANCE = 1, ORDER_PTD_CENTER = 2, ORDER_PTD_MAX = 3 };
 
-inline bool uses_blend_log(const StpSettings& s) { return s.record_blend_log != 0 && s.sort_mode == MODE_HIER; }
+inline bool uses_blend_log(const StpSettings& s) { return s.record_blend_log != 0 && (s.sort_mode == MODE_HIER || s.sort_mode == MODE_KBUFFER); }
 
 inline bool requires_depth_along_ray(const StpSettings& s) // reference rasterizer.h:66-71
 {

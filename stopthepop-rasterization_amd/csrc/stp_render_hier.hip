@@ -6,6 +6,8 @@
 
 namespace stp {
 
+
+
 #define STP_DECL(name) hipError_t name(const FrameParams& f, const RenderArgs& a, hipStream_t st, bool* handled)
 STP_DECL(launch_hier_fwd_mid8);
 STP_DECL(launch_hier_bwd_mid8);

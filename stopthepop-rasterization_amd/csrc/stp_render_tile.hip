@@ -236,15 +236,34 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
 // ------------------------------------------------------------------------------------------------
 // PPX_KBUFFER forward / backward: per-pixel sorted window keyed by depth along the pixel's own ray
 // ------------------------------------------------------------------------------------------------
-template <int WIN, bool BACKWARD>
+// MODE 0 = forward, 1 = backward that re-runs the window sort (the reference's scheme; nine atomics per blended pair),
+// 2 = training forward: additionally records every pixel's blend order in the blend log, so that the backward is the
+// replay kernel of stp_render_replay.hip (the same log format and thread -> pixel mapping as the hierarchical mode).
+constexpr int KB_FWD = 0, KB_BWD = 1, KB_FWD_RECORD = 2;
+constexpr int KB_RING = 2 * BLOCK; // list positions whose Gaussian id the recording forward keeps in LDS (two staging rounds)
+
+template <int WIN, int MODE>
 __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs a)
 {
-    __shared__ int s_id[BLOCK];
+    constexpr bool BACKWARD = MODE == KB_BWD;
+    constexpr bool RECORD = MODE == KB_FWD_RECORD;
+    __shared__ int s_id[RECORD ? KB_RING : BLOCK];
     __shared__ float2 s_xy[BLOCK];
     __shared__ float4 s_co[BLOCK];
     __shared__ float4 s_inv[3][BLOCK];
 
-    const TileCtx c = tile_ctx(a);
+    TileCtx c = tile_ctx(a);
+    if constexpr (BACKWARD) {
+        // fallback duty only when the forward recorded blend logs: just the tiles whose log overflowed
+        if (a.flag_mode == 1 && a.tile_flags[c.tile] == 0u) return;
+    }
+    const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
+    if constexpr (RECORD) { // the replay kernel's pixel of (wave, lane): wave = row of four 4x4 sub-tiles, 2x2 quads inside
+        const int sb = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
+        c.px = c.tx * TILE + 4 * sb + 2 * (m & 1) + (q & 1);
+        c.py = c.ty * TILE + 4 * w + 2 * (m >> 1) + (q >> 1);
+        c.inside = c.px < a.W && c.py < a.H;
+    }
     const float pxf = (float)c.px, pyf = (float)c.py;
     bool done = !c.inside;
     const int total = (int)(c.range.y - c.range.x);
@@ -254,19 +273,30 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
     const float3 dir = view_ray(a.inv_vp, cam, pxf, pyf, a.W, a.H);
 
-    Window<WIN> win;
+    Window<WIN> win; // payload: Gaussian id, or (recording forward) the entry's position in the tile list
     win.init();
     FwdPixel fp;
     BwdPixel bp;
     if constexpr (BACKWARD) init_bwd_pixel(bp, a, c.inside, c.px, c.py);
     else init_fwd_pixel(fp);
     uint32_t contributor = 0;
+    uint32_t* const log_base = RECORD ? a.blend_log + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
+    int nrec = 0;
+    int ring_lo = 0; // the ring holds the ids of positions [ring_lo, staged)
 
     auto blend_one = [&]() {
         if (win.num == 0) return;
         bool ok;
         if constexpr (BACKWARD) ok = blend_backward(bp, a, c.px, c.py, win.id[0], win.store[0]);
-        else ok = blend_forward(fp, a.features, win.id[0], win.store[0]);
+        else if constexpr (RECORD) {
+            const int pos = win.id[0];
+            const int id = pos >= ring_lo ? s_id[pos & (KB_RING - 1)] : (int)a.point_list[c.range.x + pos];
+            ok = blend_forward(fp, a.features, id, win.store[0]);
+            if (ok) {
+                if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (uint32_t)pos;
+                nrec++;
+            }
+        } else ok = blend_forward(fp, a.features, win.id[0], win.store[0]);
         if (!ok) { win.num--; done = true; return; }
         win.pop();
     };
@@ -276,13 +306,14 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
         const int progress = i * BLOCK + (int)threadIdx.x;
         if ((int)c.range.x + progress < (int)c.range.y) {
             const int id = (int)a.point_list[c.range.x + progress];
-            s_id[threadIdx.x] = id;
+            s_id[RECORD ? (progress & (KB_RING - 1)) : (int)threadIdx.x] = id;
             s_xy[threadIdx.x] = a.means2D[id];
             s_co[threadIdx.x] = a.conic_opacity[id];
             s_inv[0][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 0];
             s_inv[1][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 1];
             s_inv[2][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 2];
         }
+        ring_lo = max(0, (i - 1) * BLOCK); // this round overwrote the ids of round i - 2
         __syncthreads();
         const int n = min(BLOCK, todo);
         for (int j = 0; !done && j < n; j++) {
@@ -299,7 +330,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             if (alpha < ALPHA_THRESHOLD) continue;
             const float depth = depth_along_ray(f4_xyz(s_inv[0][j]), f4_xyz(s_inv[1][j]), f4_xyz(s_inv[2][j]), dir);
             if (depth < 0.0f) continue;
-            win.insert(depth, s_id[j], BACKWARD ? G : alpha);
+            win.insert(depth, RECORD ? i * BLOCK + j : s_id[j], BACKWARD ? G : alpha);
         }
     }
     if (!done)
@@ -309,10 +340,13 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
         if (c.inside) {
             const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * c.py + c.px;
             a.final_T[pid] = fp.T;
-            a.n_contrib[pid] = contributor;
+            a.n_contrib[pid] = RECORD ? (uint32_t)nrec : contributor; // (recording forward: the pixel's number of log records)
             a.out_color[pid] = fp.C[0] + fp.T * a.bg[0];
             a.out_color[N + pid] = fp.C[1] + fp.T * a.bg[1];
             a.out_color[2 * N + pid] = fp.C[2] + fp.T * a.bg[2];
+        }
+        if constexpr (RECORD) {
+            if (nrec > BLEND_LOG_DEPTH) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
         }
     }
 }
@@ -338,11 +372,11 @@ hipError_t launch_hier_rec(const FrameParams& f, const RenderArgs& a, hipStream_
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 hipError_t launch_full_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 
-template <bool BACKWARD> static hipError_t launch_kbuffer(const FrameParams& f, const RenderArgs& a, hipStream_t st)
+template <int MODE> static hipError_t launch_kbuffer(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {
     const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(BLOCK);
     const int w = f.s.queue_per_pixel; // reference forward.cu:409-425 / backward.cu:712-731
-#define STP_KB(WIN) hipLaunchKernelGGL((render_kbuffer_kernel<WIN, BACKWARD>), grid, block, 0, st, a)
+#define STP_KB(WIN) hipLaunchKernelGGL((render_kbuffer_kernel<WIN, MODE>), grid, block, 0, st, a)
     if (w <= 1) STP_KB(1);
     else if (w <= 2) STP_KB(2);
     else if (w <= 4) STP_KB(4);
@@ -366,7 +400,7 @@ hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, c
     case MODE_GLOBAL:
         hipLaunchKernelGGL(render_global_fwd_kernel, grid, block, 0, st, a);
         return hipGetLastError();
-    case MODE_KBUFFER: return launch_kbuffer<false>(f, a, st);
+    case MODE_KBUFFER: return uses_blend_log(f.s) ? launch_kbuffer<KB_FWD_RECORD>(f, a, st) : launch_kbuffer<KB_FWD>(f, a, st);
     case MODE_FULL: return launch_full_fwd(f, a, st);
     case MODE_HIER: return uses_blend_log(f.s) ? launch_hier_rec(f, a, st, err) : launch_hier_fwd(f, a, st, err);
     default: if (err) *err = "invalid sort mode"; return hipErrorInvalidValue;
@@ -384,7 +418,13 @@ hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, 
     case MODE_GLOBAL:
         hipLaunchKernelGGL(render_global_bwd_kernel, grid, block, 0, st, a);
         return hipGetLastError();
-    case MODE_KBUFFER: return launch_kbuffer<true>(f, a, st);
+    case MODE_KBUFFER:
+        if (uses_blend_log(f.s)) { // replay the forward's blend log; the re-sorting kernel only takes overflowed tiles
+            hipError_t e = launch_hier_replay(f, a, st);
+            if (e != hipSuccess) return e;
+            a.flag_mode = 1;
+        }
+        return launch_kbuffer<KB_BWD>(f, a, st);
     case MODE_HIER:
         if (uses_blend_log(f.s)) { // replay the forward's blend log; the resorting kernel only takes overflowed tiles
             hipError_t e = launch_hier_replay(f, a, st);

@@ -171,11 +171,12 @@ def test_sh_degrees_and_coefficient_counts(degree, M):
 HAZE = dict(P=3000, W=48, H=48, sigma_min=10.0, sigma_max=20.0, seed=21, opacity_range=(0.01, 0.03))
 
 
-def test_blend_log_overflow_falls_back_to_the_resorting_backward():
+@pytest.mark.parametrize("sd", [settings_dict(3, h44=True), settings_dict(2, per_pixel=16)], ids=["hier", "kbuffer16"])
+def test_blend_log_overflow_falls_back_to_the_resorting_backward(sd):
     """Thousands of faint, wide Gaussians: pixels blend far more than BLEND_LOG_DEPTH (256) entries, the recording
     forward flags those tiles and the resorting backward kernel takes them.  Result must not change."""
     sc = scenes.make_scene(**HAZE)
-    g, f = check_against_oracle(sc, settings_dict(3, h44=True))
+    g, f = check_against_oracle(sc, sd)
     flags = g.image_array("tile_flags")
     assert flags.size == 9 and flags.any(), "scene did not overflow the blend log: test is vacuous"
 
@@ -184,6 +185,9 @@ def test_blend_log_mixed_tiles():
     """Some tiles overflow, the others replay: both backward kernels write into the same gradient arrays."""
     sc = scenes.make_scene(P=5000, W=96, H=64, sigma_min=3.0, sigma_max=16.0, seed=23, opacity_range=(0.01, 0.05))
     sc.opacities[sc.means3D[:, 0] > 0.0] = 0.6  # right half of the image saturates after a few dozen blends
+    gk, _ = check_against_oracle(sc, settings_dict(2, per_pixel=8))
+    fk = gk.image_array("tile_flags")
+    assert fk.any() and not fk.all(), fk
     g, _ = check_against_oracle(sc, settings_dict(**FULL_STP), exact_state=False)
     flags = g.image_array("tile_flags")
     assert flags.any() and not flags.all(), flags
