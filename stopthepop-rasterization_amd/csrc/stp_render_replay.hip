@@ -51,6 +51,8 @@ __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// RETRIES: extra claim rounds for lanes that lose a slot to another position of the same step (see below)
+template <int RETRIES>
 __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel(const RenderArgs a)
 {
     __shared__ unsigned long long s_acc[4][9 * RW];
@@ -219,39 +221,62 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
         }
 #endif
         const int slot = (RW & (RW - 1)) == 0 ? (cur_pos & (RW - 1)) : (int)((unsigned)cur_pos % (unsigned)RW); // (cur_pos >= 0 for every lane that uses it)
-        const int owner = writer ? tag[slot] : cur_pos;
-        const bool miss = writer && owner != cur_pos;
-        if (miss) claim[slot] = lane; // several lanes may want the slot: one wins
-        wave_sync();
-        const bool won = miss && claim[slot] == lane;
+        // Every add goes through a cache slot.  Lanes whose slot belongs to another position claim it (one winner per
+        // slot), the winner hands the old sums to memory and takes the slot over.
+        auto add_fixed = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) {
+                const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
+                const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
+                atomicAdd(&acc[kk * RW + slot], (unsigned long long)qv);
+            }
+        };
+        auto claim_round = [&](bool pending) __attribute__((always_inline)) {
+            const int owner = pending ? tag[slot] : cur_pos;
+            const bool miss = pending && owner != cur_pos;
+            if (miss) claim[slot] = lane; // several lanes may want the slot: one wins
+            wave_sync();
+            const bool won = miss && claim[slot] == lane;
 #ifdef STP_REPLAY_STATS
-        { const int ne = __popcll(__ballot(won && owner >= 0)), nm = __popcll(__ballot(miss)); if (lane == 0) { atomicAdd(&g_replay_stats[7], (unsigned long long)ne); atomicAdd(&g_replay_stats[8], (unsigned long long)nm); } }
+            { const int ne = __popcll(__ballot(won && owner >= 0)), nm = __popcll(__ballot(miss)); if (lane == 0) { atomicAdd(&g_replay_stats[7], (unsigned long long)ne); atomicAdd(&g_replay_stats[8], (unsigned long long)nm); atomicAdd(&g_replay_stats[9], 1ull); } }
 #endif
-        evict_lanes(__ballot(won && owner >= 0), slot);
-        wave_sync();
-        if (won) {
-            tag[slot] = cur_pos;
-            gid[slot] = cur_id;
-        }
-        wave_sync();
+            evict_lanes(__ballot(won && owner >= 0), slot);
+            wave_sync();
+            if (won) {
+                tag[slot] = cur_pos;
+                gid[slot] = cur_id;
+            }
+            wave_sync();
+        };
+        claim_round(writer);
+        bool lost = false;
         if (writer) {
             float gmax = fabsf(g[0]);
 #pragma unroll
             for (int kk = 1; kk < 9; kk++) gmax = fmaxf(gmax, fabsf(g[kk]));
-            if (tag[slot] == cur_pos && gmax < fx_cap) {
-#pragma unroll
-                for (int kk = 0; kk < 9; kk++) {
-                    const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
-                    const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
-                    atomicAdd(&acc[kk * RW + slot], (unsigned long long)qv);
-                }
-            } else { // lost the slot to another position in this very step, or a term too large for the fixed point
-#ifdef STP_REPLAY_STATS
-                atomicAdd(&g_replay_stats[9], 1ull);
-#endif
+            if (tag[slot] == cur_pos && gmax < fx_cap) add_fixed();
+            else if (!(gmax < fx_cap)) { // a term too large for the fixed point (never seen): straight to memory
 #pragma unroll
                 for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
+            } else lost = true; // the slot went to another position of this very step
+        }
+        // Lanes that lost go round again and evict the winner in turn -- an eviction is one nine-lane atomic per four
+        // slots, far cheaper than nine single-lane atomics.  Rare when neighbouring pixels walk the list together (C2:
+        // one step in a hundred), the rule when every pixel has its own order over a long list (k-buffer, C3).
+        // Compile-time choice: the hierarchical mode runs without retries (on C2 they cost 4-6 % in code quality and
+        // one step in a hundred would use them), the k-buffer mode with three (straight-line, not a loop: with a back
+        // edge here the compiler waits for the step's prefetch loads before the loop header).
+#pragma unroll
+        for (int retry = 0; retry < RETRIES; retry++) {
+            if (__builtin_expect(__any(lost), 0)) {
+                wave_sync(); // the adds above are issued before their slot can be evicted
+                claim_round(lost);
+                if (lost && tag[slot] == cur_pos) { add_fixed(); lost = false; }
             }
+        }
+        if (lost) { // still contested: nine single-lane atomics
+#pragma unroll
+            for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
         }
     }
     wave_sync();
@@ -275,7 +300,8 @@ extern "C" int stp_debug_replay_stats(unsigned long long* out16)
 
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(render_hier_replay_kernel, dim3(f.gx * (f.ty1 - f.ty0)), dim3(256), 0, st, a);
+    if (f.s.sort_mode == MODE_KBUFFER) hipLaunchKernelGGL(render_hier_replay_kernel<3>, dim3(f.gx * (f.ty1 - f.ty0)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(render_hier_replay_kernel<0>, dim3(f.gx * (f.ty1 - f.ty0)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -9,9 +9,10 @@ import bench
 import diff_gaussian_rasterization as dgr
 from diff_gaussian_rasterization import _C, scenes
 variant = sys.argv[1] if len(sys.argv) > 1 else "full"
+workload = sys.argv[2] if len(sys.argv) > 2 else "C2"
 dev = torch.device("cuda:0")
-scene = scenes.config("C2", 1.0)
-es = bench.settings_for(variant, "C2")
+scene = scenes.config(workload, 1.0)
+es = bench.settings_for(variant, workload)
 t = lambda x: torch.tensor(x, device=dev)
 rs = dgr.GaussianRasterizationSettings(image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
     scale_modifier=1.0, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix), inv_viewprojmatrix=t(scene.inv_viewprojmatrix),
@@ -26,7 +27,7 @@ L.stp_debug_replay_stats(out)
 torch.cuda.synchronize()
 L.stp_debug_replay_stats(out)
 steps, nb, nw, dw, db = out[0], out[1], out[2], out[3], out[4]
-print(f"{variant}: wave-steps {steps}; per step: blending lanes {nb/steps:.1f}, distinct positions among them {db/steps:.1f}, "
+print(f"{workload}-{variant}: wave-steps {steps}; per step: blending lanes {nb/steps:.1f}, distinct positions among them {db/steps:.1f}, "
       f"writer lanes after quad/row pre-reduction {nw/steps:.1f}, distinct positions among writers {dw/steps:.1f}; "
       f"sum over quads of distinct positions {out[5]/steps:.1f}, sum over 16-lane rows {out[6]/steps:.1f}; "
-      f"cache: missing lanes {out[8]/steps:.2f}, evictions {out[7]/steps:.2f}, lane-adds sent to memory directly {out[9]/steps:.2f}")
+      f"cache: missing lanes {out[8]/steps:.2f}, evictions {out[7]/steps:.2f}, claim rounds {out[9]/steps:.2f}")
