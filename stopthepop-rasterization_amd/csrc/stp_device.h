@@ -57,6 +57,36 @@ __device__ __forceinline__ float quad_bcast_dyn(float v, int i)
 }
 
 // ---------------------------------------------------------------- small vector helpers
+// Arithmetic with a quad-broadcast operand folded into the instruction (VOP2 + DPP quad_perm): bcast<I>(a) OP b in
+// ONE instruction instead of a v_mov_dpp plus the operation.  The hot per-pixel evaluation of a head-queue candidate
+// consumes fifteen values that one lane of the quad fetched for all four; the compiler's DPP combiner leaves the
+// broadcasts as separate moves, so they are written out here.  Same rounding as the plain forms (v_fmac is the fused
+// multiply-add).  Callers make sure all four lanes of the quad are active and that `a` was not written by a VALU
+// instruction in the two preceding issue slots (DPP read hazard): the callers' sources come from memory loads and
+// the first use is preceded by `dpp_hazard_guard()`.
+__device__ __forceinline__ void dpp_hazard_guard() { asm volatile("s_nop 1"); }
+#define STP_DPP_OP3(NAME, INSTR)                                                                                              \
+    template <int I> __device__ __forceinline__ float NAME(float a, float b)                                                  \
+    {                                                                                                                         \
+        float r;                                                                                                              \
+        if constexpr (I == 0) asm(INSTR " %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(a), "v"(b)); \
+        else if constexpr (I == 1) asm(INSTR " %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(a), "v"(b)); \
+        else if constexpr (I == 2) asm(INSTR " %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(a), "v"(b)); \
+        else asm(INSTR " %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(a), "v"(b));  \
+        return r;                                                                                                             \
+    }
+STP_DPP_OP3(quad_mul, "v_mul_f32_dpp") // bcast<I>(a) * b
+STP_DPP_OP3(quad_sub, "v_sub_f32_dpp") // bcast<I>(a) - b
+#undef STP_DPP_OP3
+template <int I> __device__ __forceinline__ float quad_fma(float a, float b, float acc) // fma(bcast<I>(a), b, acc)
+{
+    if constexpr (I == 0) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (I == 1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (I == 2) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+
 struct Mat3 { float m[3][3]; }; // m[c][r]: column c, row r (same storage convention as the reference's vector library)
 
 __device__ __forceinline__ Mat3 mat_mul(const Mat3& a, const Mat3& b)
@@ -160,6 +190,19 @@ __device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2
     const float a1 = fmaf(p1.y, v.z, fmaf(p1.x, v.y, p0.y * v.x));
     const float a2 = fmaf(p1.z, v.z, fmaf(p1.y, v.y, p0.z * v.x));
     const float num = fmaf(p2.z, v.z, fmaf(p2.y, v.y, p2.x * v.x));
+    const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
+    const float rcp = rcp_ieee(fmaxf(0.00001f, den));
+    return num * rcp;
+}
+
+// depth_along_ray() for lane I's packed Sigma^-1 rows (c0 = [S00 S01 S02], c1 = [S11 S12 S22], c2 = Sigma^-1 (mu - cam)),
+// every product taking its broadcast operand through DPP: the same operations in the same order, bit for bit.
+template <int I> __device__ __forceinline__ float depth_along_ray_quad(float4 c0, float4 c1, float4 c2, float3 v)
+{
+    const float a0 = quad_fma<I>(c0.z, v.z, quad_fma<I>(c0.y, v.y, quad_mul<I>(c0.x, v.x)));
+    const float a1 = quad_fma<I>(c1.y, v.z, quad_fma<I>(c1.x, v.y, quad_mul<I>(c0.y, v.x)));
+    const float a2 = quad_fma<I>(c1.z, v.z, quad_fma<I>(c1.y, v.y, quad_mul<I>(c0.z, v.x)));
+    const float num = quad_fma<I>(c2.z, v.z, quad_fma<I>(c2.y, v.y, quad_mul<I>(c2.x, v.x)));
     const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
     const float rcp = rcp_ieee(fmaxf(0.00001f, den));
     return num * rcp;
