@@ -146,6 +146,11 @@ BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* nam
     b.keys_unsorted = c.take<uint64_t>(R, &off); note("keys_unsorted", off, R);
     b.sort_temp_bytes = sort_temp_bytes(R);
     b.sort_temp = c.take<char>(b.sort_temp_bytes);
+    b.entA = c.take<float4>(R, &off); note("entA", off, 4 * R);
+    b.entB = c.take<float4>(R, &off); note("entB", off, 4 * R);
+    b.entC = c.take<float4>(R, &off); note("entC", off, 4 * R);
+    b.entD = c.take<float4>(R, &off); note("entD", off, 4 * R);
+    b.entF = c.take<float4>(R, &off); note("entF", off, 4 * R);
     if (total) *total = c.total();
     if (n_names) *n_names = n;
     return b;
@@ -247,7 +252,7 @@ int stp_geometry_layout(int P, const StpSettings* settings, const char* name, si
 }
 int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count)
 {
-    NamedOffset names[8]; int n = 0;
+    NamedOffset names[16]; int n = 0;
     carve_binning(nullptr, (size_t)(R > 0 ? R : 0), nullptr, names, &n);
     return find_name(names, n, name, offset, count);
 }
@@ -347,6 +352,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_DEBUG_SYNC("sort");
     STP_TRY(launch_ranges(f, b, img, R, st), "tile ranges");
     STP_DEBUG_SYNC("ranges");
+    STP_TRY(launch_gather_entries(f, g, b, R, st), "entry gather");
+    STP_DEBUG_SYNC("entry gather");
     g_timer.mark(3, st);
 
     std::string err;

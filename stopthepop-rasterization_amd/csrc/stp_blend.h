@@ -17,6 +17,11 @@ struct RenderArgs {
     const float4* conic_opacity;
     const float4* cov3D_inv;
     const float* features; // colours, P x 3
+    const float4* entA;    // per-entry data in list order (BinningState::entA..entF), per-pixel-sort modes only
+    const float4* entB;
+    const float4* entC;
+    const float4* entD;
+    const float4* entF;
     const float* inv_vp;
     const float* cam;
     const float* bg;

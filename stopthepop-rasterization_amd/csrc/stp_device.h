@@ -208,6 +208,23 @@ template <int I> __device__ __forceinline__ float depth_along_ray_quad(float4 c0
     return num * rcp;
 }
 
+// The same for an entry record (BinningState: A = (S00 S01 S02 S11), B = (S12 S22 q.x q.y), C = (q.z . . .)).
+template <int I> __device__ __forceinline__ float depth_along_ray_quad_ent(float4 A, float4 B, float4 C, float3 v)
+{
+    const float a0 = quad_fma<I>(A.z, v.z, quad_fma<I>(A.y, v.y, quad_mul<I>(A.x, v.x)));
+    const float a1 = quad_fma<I>(B.x, v.z, quad_fma<I>(A.w, v.y, quad_mul<I>(A.y, v.x)));
+    const float a2 = quad_fma<I>(B.y, v.z, quad_fma<I>(B.x, v.y, quad_mul<I>(A.z, v.x)));
+    const float num = quad_fma<I>(C.x, v.z, quad_fma<I>(B.w, v.y, quad_mul<I>(B.z, v.x)));
+    const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
+    const float rcp = rcp_ieee(fmaxf(0.00001f, den));
+    return num * rcp;
+}
+// depth_along_ray() on an entry record
+__device__ __forceinline__ float depth_along_ray_ent(float4 A, float4 B, float4 C, float3 v)
+{
+    return depth_along_ray(make_float3(A.x, A.y, A.z), make_float3(A.w, B.x, B.y), make_float3(B.z, B.w, C.x), v);
+}
+
 __device__ __forceinline__ float3 f4_xyz(float4 a) { return make_float3(a.x, a.y, a.z); }
 
 // reference auxiliary.h:71-81 and stopthepop_common.cuh:68-74; normalize(v) = v * (1/sqrt(v.v))

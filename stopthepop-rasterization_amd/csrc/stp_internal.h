@@ -75,6 +75,15 @@ struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
     uint64_t* keys_unsorted;
     char* sort_temp;
     size_t sort_temp_bytes;
+    // Per-entry data in LIST ORDER (no counterpart in the reference, which gathers by Gaussian id wherever it needs
+    // an entry's data): written once per frame by gather_entries_kernel, read with unit stride by the per-pixel-sort
+    // render kernels.  A = (S00 S01 S02 S11), B = (S12 S22 q.x q.y), C = (q.z mean2D.x mean2D.y id), D = conic + opacity,
+    // F = (r g b .), with S = Sigma^-1 and q = Sigma^-1 (mu - cam).
+    float4* entA;
+    float4* entB;
+    float4* entC;
+    float4* entD;
+    float4* entF;
 };
 
 struct NamedOffset { const char* name; size_t offset; size_t count; };
@@ -127,6 +136,7 @@ hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t
 hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, hipStream_t st);
 hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, hipStream_t st);
 hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st);
+hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st);
 hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
                                  float* out_color, hipStream_t st, std::string* err);
 hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,

@@ -11,8 +11,8 @@
 //
 // Layout: one 256-thread workgroup per tile, thread -> pixel mapping identical to the forward (wave = row of four
 // 4x4 sub-tiles), log laid out [tile][wave][k][lane] so that the 64 lanes of a wave read record k with one
-// coalesced 256-byte load.  No sorting state: the kernel is a straight loop over k with a one-deep prefetch of
-// the next record, the per-Gaussian data gathered from L2, and the nine gradient terms summed in a per-wave
+// coalesced 256-byte load.  No sorting state: the kernel is a straight loop over k with the next record prefetched,
+// the entry's data read from the list-ordered entry arrays, and the nine gradient terms summed in a per-wave
 // direct-mapped LDS cache of 64-bit fixed-point sums (see stp_render_hier.inc for why not fp32 LDS atomics):
 // slot = list position mod 128, tagged; the sums of a slot go to memory (nine global atomics) only when another
 // list position claims the slot, or at the end.
@@ -128,26 +128,34 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
         }
     };
 
-    // Three dependent loads lead to a blend: log record -> Gaussian id (point_list) -> its data.  They are software
-    // pipelined one step apart, so that an iteration waits for one memory latency, not three: when iteration k
-    // starts, the data of record k, the id of record k+1 and the position of record k+2 are in registers (or in
+    // Two dependent loads lead to a blend: log record (list position) -> the entry's record in the list-ordered entry
+    // arrays (mean, Gaussian id, conic/opacity, colour: BinningState::entC/entD/entF).  They are software pipelined one
+    // step apart: when iteration k starts, the data of record k and the position of record k+1 are in registers (or in
     // flight since the previous iteration).
+    const float4* const eC = a.entC + range.x;
+    const float4* const eD = a.entD + range.x;
+    const float4* const eF = a.entF + range.x;
     auto log_at = [&](int k) __attribute__((always_inline)) { return (k < n) ? (int)log_base[(size_t)k * 64] : -1; };
-    auto id_at = [&](int p) __attribute__((always_inline)) { return (p >= 0) ? (int)a.point_list[range.x + p] : 0; };
-    int pos = log_at(0), pos1 = log_at(1), pos2 = log_at(2);
-    int id = id_at(pos), id1 = id_at(pos1);
-    FrontData fd = load_front(a, id); // (id 0 where there is no record: a harmless read, and no branch around the loads)
+    struct Entry { float4 c, d, f; };
+    auto entry_at = [&](int p) __attribute__((always_inline)) { // (position 0 where there is no record: a harmless read, no branch)
+        const int q = max(p, 0);
+        return Entry{eC[q], eD[q], eF[q]};
+    };
+    int pos = log_at(0), pos1 = log_at(1);
+    Entry en = entry_at(pos);
     for (int k = 0; k < nmax; k++) {
         const bool have = k < n;
-        const FrontData cur_fd = fd;
-        const int cur_pos = pos, cur_id = id;
+        const Entry cur = en;
+        const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
         // issue the next round of loads before touching this step's data
-        fd = load_front(a, id1);
-        const int id2 = (k + 2 < n) ? (int)a.point_list[range.x + pos2] : 0;
-        const int pos3 = (k + 3 < n) ? (int)log_base[(size_t)(k + 3) * 64] : -1;
-        pos = pos1; id = id1;
-        pos1 = pos2; id1 = id2;
-        pos2 = pos3;
+        en = entry_at(pos1);
+        const int pos2 = (k + 2 < n) ? (int)log_base[(size_t)(k + 2) * 64] : -1;
+        pos = pos1;
+        pos1 = pos2;
+        FrontData cur_fd;
+        cur_fd.co = cur.d;
+        cur_fd.xy = make_float2(cur.c.y, cur.c.z);
+        cur_fd.c[0] = cur.f.x; cur_fd.c[1] = cur.f.y; cur_fd.c[2] = cur.f.z;
         float g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
         bool ok = false;
         if (have) {

@@ -360,6 +360,7 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
     a.ranges = img.ranges; a.point_list = b.point_list; a.means2D = g.means2D; a.conic_opacity = g.conic_opacity;
     a.cov3D_inv = g.cov3D_inv; a.features = f.colors_precomp ? f.colors_precomp : g.rgb; // reference rasterizer_impl.cu:367,473
     a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.bg = f.background;
+    a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     a.final_T = img.final_T; a.n_contrib = img.n_contrib;
     a.blend_log = img.blend_log; a.tile_flags = img.tile_flags; a.flag_mode = 0;
     return a;
