@@ -103,6 +103,7 @@ GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total,
     g.means2D = c.take<float2>(P, &off); note("means2D", off, 2 * P);
     g.cov3D = c.take<float>(6 * P, &off); note("cov3D", off, 6 * P);
     if (with_inv) { g.cov3D_inv = c.take<float4>(3 * P, &off); note("cov3D_inv", off, 12 * P); }
+    if (with_inv) { g.gpack = c.take<float4>(4 * P, &off); note("gpack", off, 16 * P); }
     g.conic_opacity = c.take<float4>(P, &off); note("conic_opacity", off, 4 * P);
     g.rgb = c.take<float>(3 * P, &off); note("rgb", off, 3 * P);
     g.tiles_touched = c.take<uint32_t>(P, &off); note("tiles_touched", off, P);
@@ -246,7 +247,7 @@ static int find_name(const NamedOffset* names, int n, const char* name, size_t* 
 }
 int stp_geometry_layout(int P, const StpSettings* settings, const char* name, size_t* offset, size_t* count)
 {
-    NamedOffset names[16]; int n = 0;
+    NamedOffset names[24]; int n = 0;
     carve_geometry(nullptr, (size_t)P, settings ? requires_depth_along_ray(*settings) : true, nullptr, names, &n);
     return find_name(names, n, name, offset, count);
 }

@@ -52,6 +52,8 @@ struct GeometryState {
     float2* means2D;         // P
     float* cov3D;            // 6P
     float4* cov3D_inv;       // 3P, only if requires_depth_along_ray
+    float4* gpack;           // 4P, only if requires_depth_along_ray: A, B, C (id slot unused), D of the entry records, packed per
+                             //     Gaussian so that gather_entries_kernel reads one contiguous 64-byte line per entry
     float4* conic_opacity;   // P
     float* rgb;              // 3P
     uint32_t* tiles_touched; // P

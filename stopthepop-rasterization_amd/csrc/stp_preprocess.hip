@@ -227,6 +227,14 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     a.g.means2D[idx] = mean2D;
     a.g.conic_opacity[idx] = co;
     a.g.tiles_touched[idx] = (uint32_t)tile_count;
+    if (a.g.gpack != nullptr) { // the same values once more, as one 64-byte line per Gaussian (see gather_entries_kernel)
+        const float4 s0 = a.g.cov3D_inv[3 * (size_t)idx + 0], s1 = a.g.cov3D_inv[3 * (size_t)idx + 1], s2 = a.g.cov3D_inv[3 * (size_t)idx + 2];
+        float4* const gp = a.g.gpack + 4 * (size_t)idx;
+        gp[0] = make_float4(s0.x, s0.y, s0.z, s1.x);
+        gp[1] = make_float4(s1.y, s1.z, s2.x, s2.y);
+        gp[2] = make_float4(s2.z, mean2D.x, mean2D.y, 0.0f);
+        gp[3] = co;
+    }
 }
 
 struct DupArgs {
@@ -371,20 +379,19 @@ hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const Imag
 // entry gathers its Gaussian's Sigma^-1 pack, conic/opacity, 2D mean and colour ONCE; afterwards every consumer
 // (batch staging, mid and head feeds, blends, the replay backward) reads them with unit stride inside its tile's
 // segment instead of gathering by Gaussian id from four arrays each time.
-__global__ void __launch_bounds__(256) gather_entries_kernel(int R, const uint32_t* __restrict__ point_list, const float4* __restrict__ cov3D_inv,
-                                                             const float4* __restrict__ conic_opacity, const float2* __restrict__ means2D,
+__global__ void __launch_bounds__(256) gather_entries_kernel(int R, const uint32_t* __restrict__ point_list, const float4* __restrict__ gpack,
                                                              const float* __restrict__ features, float4* __restrict__ entA, float4* __restrict__ entB,
                                                              float4* __restrict__ entC, float4* __restrict__ entD, float4* __restrict__ entF)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const int id = (int)point_list[i];
-    const float4 s0 = cov3D_inv[3 * (size_t)id + 0], s1 = cov3D_inv[3 * (size_t)id + 1], s2 = cov3D_inv[3 * (size_t)id + 2];
-    const float2 xy = means2D[id];
-    entA[i] = make_float4(s0.x, s0.y, s0.z, s1.x);
-    entB[i] = make_float4(s1.y, s1.z, s2.x, s2.y);
-    entC[i] = make_float4(s2.z, xy.x, xy.y, __int_as_float(id));
-    entD[i] = conic_opacity[id];
+    const float4* __restrict__ gp = gpack + 4 * (size_t)id; // one 64-byte line written by preprocess_kernel
+    const float4 pa = gp[0], pb = gp[1], pc = gp[2], pd = gp[3];
+    entA[i] = pa;
+    entB[i] = pb;
+    entC[i] = make_float4(pc.x, pc.y, pc.z, __int_as_float(id));
+    entD[i] = pd;
     entF[i] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1], features[3 * (size_t)id + 2], 0.0f);
 }
 
@@ -392,8 +399,8 @@ hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, c
 {
     if (R <= 0 || (f.s.sort_mode != MODE_HIER && f.s.sort_mode != MODE_KBUFFER)) return hipSuccess;
     const float* features = f.colors_precomp ? f.colors_precomp : g.rgb;
-    hipLaunchKernelGGL(gather_entries_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, b.point_list, g.cov3D_inv, g.conic_opacity, g.means2D,
-                       features, b.entA, b.entB, b.entC, b.entD, b.entF);
+    hipLaunchKernelGGL(gather_entries_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, b.point_list, g.gpack, features, b.entA, b.entB, b.entC,
+                       b.entD, b.entF);
     return hipGetLastError();
 }
 
