@@ -240,17 +240,18 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
 // 2 = training forward: additionally records every pixel's blend order in the blend log, so that the backward is the
 // replay kernel of stp_render_replay.hip (the same log format and thread -> pixel mapping as the hierarchical mode).
 constexpr int KB_FWD = 0, KB_BWD = 1, KB_FWD_RECORD = 2;
-constexpr int KB_RING = 2 * BLOCK; // list positions whose Gaussian id the recording forward keeps in LDS (two staging rounds)
 
 template <int WIN, int MODE>
 __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs a)
 {
     constexpr bool BACKWARD = MODE == KB_BWD;
     constexpr bool RECORD = MODE == KB_FWD_RECORD;
-    __shared__ int s_id[RECORD ? KB_RING : BLOCK];
-    __shared__ float2 s_xy[BLOCK];
-    __shared__ float4 s_co[BLOCK];
-    __shared__ float4 s_inv[3][BLOCK];
+    // one staging round = BLOCK entry records (A, B, C, D of BinningState), read with unit stride from the list-ordered
+    // entry arrays; the forward passes carry the list position through the window, the backward pass the Gaussian id
+    __shared__ float4 s_A[BLOCK];
+    __shared__ float4 s_B[BLOCK];
+    __shared__ float4 s_C[BLOCK];
+    __shared__ float4 s_D[BLOCK];
 
     TileCtx c = tile_ctx(a);
     if constexpr (BACKWARD) {
@@ -282,21 +283,24 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     uint32_t contributor = 0;
     uint32_t* const log_base = RECORD ? a.blend_log + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
     int nrec = 0;
-    int ring_lo = 0; // the ring holds the ids of positions [ring_lo, staged)
+    const float4* const eF = a.entF + c.range.x;
 
     auto blend_one = [&]() {
         if (win.num == 0) return;
         bool ok;
         if constexpr (BACKWARD) ok = blend_backward(bp, a, c.px, c.py, win.id[0], win.store[0]);
-        else if constexpr (RECORD) {
+        else {
             const int pos = win.id[0];
-            const int id = pos >= ring_lo ? s_id[pos & (KB_RING - 1)] : (int)a.point_list[c.range.x + pos];
-            ok = blend_forward(fp, a.features, id, win.store[0]);
-            if (ok) {
-                if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (uint32_t)pos;
-                nrec++;
+            const float4 colr = eF[pos];
+            const float col[3] = {colr.x, colr.y, colr.z};
+            ok = blend_forward_c(fp, col, win.store[0]);
+            if constexpr (RECORD) {
+                if (ok) {
+                    if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (uint32_t)pos;
+                    nrec++;
+                }
             }
-        } else ok = blend_forward(fp, a.features, win.id[0], win.store[0]);
+        }
         if (!ok) { win.num--; done = true; return; }
         win.pop();
     };
@@ -305,32 +309,29 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
         if (__syncthreads_and(done)) break;
         const int progress = i * BLOCK + (int)threadIdx.x;
         if ((int)c.range.x + progress < (int)c.range.y) {
-            const int id = (int)a.point_list[c.range.x + progress];
-            s_id[RECORD ? (progress & (KB_RING - 1)) : (int)threadIdx.x] = id;
-            s_xy[threadIdx.x] = a.means2D[id];
-            s_co[threadIdx.x] = a.conic_opacity[id];
-            s_inv[0][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 0];
-            s_inv[1][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 1];
-            s_inv[2][threadIdx.x] = a.cov3D_inv[3 * (size_t)id + 2];
+            const size_t gi = (size_t)c.range.x + progress;
+            s_A[threadIdx.x] = a.entA[gi];
+            s_B[threadIdx.x] = a.entB[gi];
+            s_C[threadIdx.x] = a.entC[gi];
+            s_D[threadIdx.x] = a.entD[gi];
         }
-        ring_lo = max(0, (i - 1) * BLOCK); // this round overwrote the ids of round i - 2
         __syncthreads();
         const int n = min(BLOCK, todo);
         for (int j = 0; !done && j < n; j++) {
             if (win.num == WIN) blend_one(); // before the next candidate is looked at
             if (done) break;
             contributor++;
-            const float2 xy = s_xy[j];
-            const float4 co = s_co[j];
-            const float dx = xy.x - pxf, dy = xy.y - pyf;
+            const float4 eCj = s_C[j];
+            const float4 co = s_D[j];
+            const float dx = eCj.y - pxf, dy = eCj.z - pyf;
             const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
             if (power > 0.0f) continue;
             const float G = exp_blend(power);
             const float alpha = fminf(0.99f, co.w * G);
             if (alpha < ALPHA_THRESHOLD) continue;
-            const float depth = depth_along_ray(f4_xyz(s_inv[0][j]), f4_xyz(s_inv[1][j]), f4_xyz(s_inv[2][j]), dir);
+            const float depth = depth_along_ray_ent(s_A[j], s_B[j], eCj, dir);
             if (depth < 0.0f) continue;
-            win.insert(depth, RECORD ? i * BLOCK + j : s_id[j], BACKWARD ? G : alpha);
+            win.insert(depth, BACKWARD ? __float_as_int(eCj.w) : i * BLOCK + j, BACKWARD ? G : alpha);
         }
     }
     if (!done)
