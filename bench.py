@@ -165,7 +165,7 @@ def main():
         if not fwd_only and not args.train_forward_only:
             (color * w_img).sum().backward()
         elif args.train_forward_only:
-            _C.release_scratch(color.grad_fn.saved_tensors[11])  # nobody will replay this log: hand the buffer back
+            _C.release_scratch(color.grad_fn.saved_tensors[11]); _C.release_scratch(color.grad_fn.saved_tensors[10])  # nobody will replay this log: hand the buffers back
 
     def barrier():
         if dist is not None:

@@ -43,6 +43,12 @@ namespace {
 #define STP_REPLAY_OCC 4
 #endif
 constexpr int RW = STP_REPLAY_RW; // cache slots per wave
+// Tiles whose list is at most DIRECT_CAP entries long need no cache at all: the workgroup's LDS holds one set of sums
+// for EVERY list position (9 x 512 x 8 B = 36 KB, the same footprint as the four per-wave caches), a blend adds to
+// acc[term][position] directly -- no tags, no claim protocol, no evictions -- and the sums leave the chip once, at
+// the end.  C2 (321 entries per tile on average, 406 at most) runs entirely on this path.
+constexpr int DIRECT_CAP = 512;
+constexpr int LDS_WORDS64 = (4 * 9 * RW * 8 + 3 * 4 * RW * 4 + 7) / 8 > 9 * DIRECT_CAP ? (4 * 9 * RW * 8 + 3 * 4 * RW * 4 + 7) / 8 : 9 * DIRECT_CAP;
 
 __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
 {
@@ -55,10 +61,8 @@ __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
 template <int RETRIES>
 __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel(const RenderArgs a)
 {
-    __shared__ unsigned long long s_acc[4][9 * RW];
-    __shared__ int s_tag[4][RW];
-    __shared__ int s_claim[4][RW];
-    __shared__ int s_gid[4][RW]; // Gaussian id of the slot's owner (saves the eviction a dependent point_list load)
+    __shared__ unsigned long long s_raw[LDS_WORDS64]; // cached path: acc[4][9*RW], tag/claim/gid[4][RW]; direct path: acc[9][DIRECT_CAP]
+    __shared__ float s_md[4];
 
     const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
     const int s = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
@@ -70,14 +74,21 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
     const int px = tile_x * TILE + 4 * s + 2 * (m & 1) + (q & 1), py = tile_y * TILE + 4 * w + 2 * (m >> 1) + (q >> 1);
     const bool inside = px < a.W && py < a.H;
 
-    unsigned long long* const acc = s_acc[w];
-    int* const tag = s_tag[w];
-    int* const claim = s_claim[w];
-    int* const gid = s_gid[w];
-    for (int i = lane; i < RW; i += 64) {
-        tag[i] = -1;
+    const int list_len = (int)(range.y - range.x);
+    const bool direct = list_len <= DIRECT_CAP; // workgroup-uniform
+    unsigned long long* const acc = s_raw + w * 9 * RW;
+    int* const tag = reinterpret_cast<int*>(s_raw + 4 * 9 * RW) + w * RW;
+    int* const claim = tag + 4 * RW;
+    int* const gid = tag + 8 * RW; // Gaussian id of the slot's owner
+    unsigned long long* const dacc = s_raw; // direct path: [term][position]
+    if (direct) {
+        for (int i = (int)threadIdx.x; i < 9 * DIRECT_CAP; i += 256) dacc[i] = 0ull;
+    } else {
+        for (int i = lane; i < RW; i += 64) {
+            tag[i] = -1;
 #pragma unroll
-        for (int k = 0; k < 9; k++) acc[k * RW + i] = 0ull;
+            for (int k = 0; k < 9; k++) acc[k * RW + i] = 0ull;
+        }
     }
 
     BwdPixel bp;
@@ -90,7 +101,11 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
         nmax = max(nmax, __shfl_xor(nmax, off));
         md = fmaxf(md, __shfl_xor(md, off));
     }
-    // fixed-point scale of this wave's sums (stp_render_hier.inc: "on-chip gradient window")
+    // fixed-point scale of the sums (stp_render_hier.inc: "on-chip gradient window"): one for the workgroup, because
+    // the direct path shares its accumulators between the four waves
+    if (lane == 0) s_md[w] = md;
+    __syncthreads(); // (also: the accumulators are zeroed)
+    md = fmaxf(fmaxf(s_md[0], s_md[1]), fmaxf(s_md[2], s_md[3]));
     int md_exp = 0;
     if (md > 0.0f && md < 3.0e38f) (void)frexpf(md, &md_exp);
     const double fx_scale = ldexp(1.0, 31 - md_exp), fx_inv = ldexp(1.0, md_exp - 31);
@@ -164,6 +179,25 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
             const float G = exp_blend(power);
             ok = blend_backward_terms(bp, a, px, py, cur_fd, G, g);
             if (!ok) n = k; // (an ulp of difference against the forward's transmittance: stop where it says so)
+        }
+        if (direct) { // every list position has its own sums in LDS: nine adds, nothing else
+            if (ok) {
+                float gmax = fabsf(g[0]);
+#pragma unroll
+                for (int kk = 1; kk < 9; kk++) gmax = fmaxf(gmax, fabsf(g[kk]));
+                if (gmax < fx_cap) {
+#pragma unroll
+                    for (int kk = 0; kk < 9; kk++) {
+                        const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
+                        const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
+                        atomicAdd(&dacc[kk * DIRECT_CAP + cur_pos], (unsigned long long)qv);
+                    }
+                } else { // a term too large for the fixed point (never seen): straight to memory
+#pragma unroll
+                    for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
+                }
+            }
+            continue;
         }
         // ---- accumulate (converged code: every lane of the wave is here) ----
         // Neighbouring pixels blend the same entry at the same step more often than not: sum the terms of a
@@ -286,6 +320,16 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
 #pragma unroll
             for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
         }
+    }
+    if (direct) { // the sums of every position leave the chip once: 16-lane group = one position, nine lanes = its nine sums
+        __syncthreads();
+        for (int p = (int)(threadIdx.x >> 4); p < list_len; p += 16) {
+            if (term < 9) {
+                const long long v = (long long)dacc[term * DIRECT_CAP + p];
+                if (v != 0) atomicAdd(grad_slot(a, __float_as_int(eC[p].w), term), (float)((double)v * fx_inv));
+            }
+        }
+        return;
     }
     wave_sync();
     for (int base = 0; base < RW; base += 64) { // final flush: every slot that has an owner

@@ -136,13 +136,15 @@ def _stream_ptr(device) -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
-# The training forward's image buffer carries the blend log (1 KiB per pixel of the tile grid, 2.1 GB at 1080p).
+# The binning buffer (tile lists + list-ordered entry records, ~100 B per entry) and the training forward's image
+# buffer are large.  The latter carries the blend log (1 KiB per pixel of the tile grid, 2.1 GB at 1080p).
 # Cycling a block of that size through torch's caching allocator every step invites splitting: smaller requests
 # carve pieces off the free block, the next forward finds no 2 GB hole and the allocator falls back to hipMalloc
 # (tens of ms per step, reserved memory growing by 2 GB a step -- observed on MI355X).  Buffers of this class are
 # therefore kept on a small free list of our own: handed out by the forward, handed back by the backward.
 _BIG_BYTES = 256 << 20
-_BIG_KEEP = 2                # free buffers kept per device
+_BIG_STEP = 64 << 20
+_BIG_KEEP = 4                # free buffers kept per device
 _big_free = {}               # device index -> [tensor, ...]
 _big_generation = {}         # data_ptr -> how many times the buffer at this address was handed out
 
@@ -159,9 +161,13 @@ class _Resizer:
         try:
             nbytes = int(nbytes)
             if self.pooled and nbytes >= _BIG_BYTES:
+                # capacity in steps of 64 MiB, so that a buffer whose size follows the number of tile-list entries
+                # (it changes a little from view to view) finds its predecessor on the free list
+                cap = (nbytes + _BIG_STEP - 1) // _BIG_STEP * _BIG_STEP
                 free = _big_free.setdefault(self.tensor.device.index, [])
-                hit = next((i for i, t in enumerate(free) if t.numel() == nbytes), None)
-                self.tensor = free.pop(hit) if hit is not None else torch.empty(nbytes, dtype=torch.uint8, device=self.tensor.device)
+                fits = [i for i, t in enumerate(free) if nbytes <= t.numel() <= cap + cap // 4]
+                hit = min(fits, key=lambda i: free[i].numel()) if fits else None
+                self.tensor = free.pop(hit) if hit is not None else torch.empty(cap, dtype=torch.uint8, device=self.tensor.device)
                 ptr = self.tensor.data_ptr()
                 _big_generation[ptr] = _big_generation.get(ptr, 0) + 1
                 return ptr
@@ -218,7 +224,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
     radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    geom, binning, img = _Resizer(dev), _Resizer(dev), _Resizer(dev, pooled=True)
+    geom, binning, img = _Resizer(dev), _Resizer(dev, pooled=True), _Resizer(dev, pooled=True)
     rendered = 0
     if P != 0:
         M = int(sh.size(1)) if sh.numel() != 0 else 0

@@ -101,7 +101,7 @@ class _RasterizeGaussians(torch.autograd.Function):
             out = _C.rasterize_gaussians_backward(*args)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
-        _C.release_scratch(imgBuffer)  # the blend log goes back to the library's free list
+        _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)  # the blend log goes back to the library's free list
         # one gradient per forward input, in forward's order
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)

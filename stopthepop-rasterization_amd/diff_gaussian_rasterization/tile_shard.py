@@ -144,7 +144,7 @@ class _ShardedRasterize(torch.autograd.Function):
         dist.all_reduce(used)
         records[:, :RECORD_USED] = used
         out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
-        _C.release_scratch(imgBuffer)
+        _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
