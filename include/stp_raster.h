@@ -51,7 +51,7 @@ typedef struct StpSettings {
     int32_t tile_y0;
     int32_t tile_y1;
     /* Extension (not in the reference): hierarchical mode only.  When non-zero the forward also records, per
-       pixel, the order in which it blended its Gaussians (4 bytes per blended pair, 1 KiB per pixel, inside the
+       pixel, the order in which it blended its Gaussians (2 bytes per blended pair, 512 B per pixel, inside the
        image buffer); a backward called with the same flag replays that log instead of re-running the resort
        (the re-sorting backward still handles tiles whose log overflowed).  Results are the same sums in a
        different order.  Set it for training forwards; leave it 0 for inference. */
@@ -148,7 +148,7 @@ int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Sizes of the three scratch buffers (the reference's `required<State>()`, rasterizer_impl.h:68-75). */
 size_t stp_geometry_buffer_size(int P, const StpSettings* settings);
 size_t stp_binning_buffer_size(int R);
-size_t stp_image_buffer_size(int width, int height); /* without the optional blend log (+ 1 KiB per tile pixel) */
+size_t stp_image_buffer_size(int width, int height); /* without the optional blend log (+ 512 B per tile pixel) */
 
 /* Introspection of the (otherwise opaque) scratch buffers, for parity tests and debugging.
    Fills byte offset and element count of a named sub-array; returns 0 or STP_ERR_INVALID_ARGUMENT.

@@ -127,7 +127,7 @@ ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* to
     s.ranges = c.take<uint2>(T, &off); note("ranges", off, 2 * T);
     if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 4 bytes per pixel
         s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
-        s.blend_log = c.take<uint32_t>(T * 256 * 256, &off); note("blend_log", off, T * 256 * 256);
+        s.blend_log = c.take<uint32_t>(T * 256 * 256 / 2, &off); note("blend_log", off, T * 256 * 256); // T x 4 waves x 256 records x 64 lanes, 2 B each
     }
     if (total) *total = c.total();
     if (n_names) *n_names = n;

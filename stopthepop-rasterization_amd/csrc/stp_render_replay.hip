@@ -3,8 +3,8 @@
 // No counterpart in the reference: its backward (hierarchical_render.cuh:1038-1175) re-runs the complete
 // three-level resort to rediscover the order in which every pixel blended its Gaussians.  MI355X has 288 GB of
 // HBM, so the training forward (render_hier_kernel<..., MODE_FWD_RECORD>) simply writes that order down --
-// 4 bytes (the tile-list position) per blended (pixel, Gaussian) pair, BLEND_LOG_DEPTH = 256 records per pixel,
-// 1 KiB per pixel, 2.1 GB at 1080p -- and this kernel walks each pixel's log front to back.  The gradient
+// 2 bytes (the tile-list position) per blended (pixel, Gaussian) pair, BLEND_LOG_DEPTH = 256 records per pixel,
+// 512 B per pixel, 1.07 GB at 1080p -- and this kernel walks each pixel's log front to back.  The gradient
 // maths per pair is the reference's (blend_backward_terms); the result is the same sum in a different order.
 // Tiles whose log overflowed (a pixel with more than 256 blended entries) are flagged by the forward and left
 // to the resorting backward kernel, which then runs only on those tiles.
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
     const float fx_cap = ldexpf(1.0f, min(md_exp + 20, 126));
     wave_sync();
 
-    const uint32_t* const log_base = a.blend_log + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane;
+    const log_t* const log_base = reinterpret_cast<const log_t*>(a.blend_log) + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane;
     const float pxf = (float)px, pyf = (float)py;
 
     // Hand the sums of up to four slots to memory with ONE atomic instruction: the 16-lane group g takes the

@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     if constexpr (BACKWARD) init_bwd_pixel(bp, a, c.inside, c.px, c.py);
     else init_fwd_pixel(fp);
     uint32_t contributor = 0;
-    uint32_t* const log_base = RECORD ? a.blend_log + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
+    log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(a.blend_log) + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
     int nrec = 0;
     const float4* const eF = a.entF + c.range.x;
 
@@ -296,7 +296,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             ok = blend_forward_c(fp, col, win.store[0]);
             if constexpr (RECORD) {
                 if (ok) {
-                    if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (uint32_t)pos;
+                    if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (log_t)pos;
                     nrec++;
                 }
             }
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             a.out_color[2 * N + pid] = fp.C[2] + fp.T * a.bg[2];
         }
         if constexpr (RECORD) {
-            if (nrec > BLEND_LOG_DEPTH) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
+            if (nrec > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
         }
     }
 }

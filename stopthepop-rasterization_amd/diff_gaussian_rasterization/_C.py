@@ -137,7 +137,7 @@ def _stream_ptr(device) -> ctypes.c_void_p:
 
 
 # The binning buffer (tile lists + list-ordered entry records, ~100 B per entry) and the training forward's image
-# buffer are large.  The latter carries the blend log (1 KiB per pixel of the tile grid, 2.1 GB at 1080p).
+# buffer are large.  The latter carries the blend log (512 B per pixel of the tile grid, 1.07 GB at 1080p).
 # Cycling a block of that size through torch's caching allocator every step invites splitting: smaller requests
 # carve pieces off the free block, the next forward finds no 2 GB hole and the allocator falls back to hipMalloc
 # (tens of ms per step, reserved memory growing by 2 GB a step -- observed on MI355X).  Buffers of this class are
@@ -318,7 +318,7 @@ _GEOM_TYPES = {"depths": torch.float32, "clamped": torch.uint8, "radii": torch.i
                "point_offsets": torch.int32}
 _BIN_TYPES = {"point_list": torch.int32, "point_list_unsorted": torch.int32, "keys": torch.int64, "keys_unsorted": torch.int64}
 _IMG_TYPES = {"final_T": torch.float32, "n_contrib": torch.int32, "ranges": torch.int32, "tile_flags": torch.int32,
-              "blend_log": torch.int32}  # the last two exist only in a buffer of a recording forward
+              "blend_log": torch.int16}  # the last two exist only in a buffer of a recording forward
 
 
 def _view(buf: torch.Tensor, off: int, count: int, dtype) -> torch.Tensor:

@@ -212,7 +212,7 @@ def test_forward_without_grad_records_nothing():
     W, H = sc.W, sc.H
     n_plain = g.img.numel()
     g2 = GpuRun(sc, settings_dict(3), backward=True)
-    assert g2.img.numel() >= n_plain + ((W + 15) // 16) * ((H + 15) // 16) * 256 * 256 * 4
+    assert g2.img.numel() >= n_plain + ((W + 15) // 16) * ((H + 15) // 16) * 256 * 256 * 2
     assert np.array_equal(g.color, g2.color)
 
 
