@@ -63,18 +63,22 @@ def algorithmic_bytes(P, P_v, R, N, T, M, S, mode_hier, K, E, sh, B=0):
     S = 1 if the mode needs Sigma^-1, K/E = per-tile-depth / culling extras of duplicate, B = blended
     (pixel, entry) pairs recorded in the blend log (hierarchical training forward; 0 otherwise)."""
     b = {}
-    b["preprocess"] = P * (44 + 8) + P_v * (12 * M * sh + 60 + 48 * S + 15 * sh)
+    b["preprocess"] = P * (44 + 8) + P_v * (12 * M * sh + 60 + (48 + 64) * S + 15 * sh)
     b["scan"] = 8 * P
     b["duplicate"] = 8 * P + P_v * (20 + 16 * E + 48 * K) + 12 * R
     b["sort"] = 24 * R
     b["ranges"] = 8 * R + 16 * T
-    # forward render: every list entry's id + conic/opacity + mean + Sigma^-1 pack + colour once per tile, the pixel outputs,
-    # and (recording forward) the 4-byte log record of every blended pair + n_contrib + tile flags
-    b["render_fwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (0 if mode_hier else 4)) + (4 * B + 4 * N + 4 * T if B else 0)
-    b["zero_fill"] = P * (64 + 44 + 12 * M + 64)
-    if B:   # replay backward: the log, the per-entry data that is blended (id, conic/opacity, mean, colour), the pixel state,
+    # per-pixel-sort modes (S): the list-ordered entry records (80 B each) are gathered once (id + the Gaussian's packed
+    # 64-byte line + colour in, record out) and are what the render kernels read; GLOBAL reads by Gaussian id
+    b["gather"] = R * (4 + 64 + 12 + 80) if S else 0
+    per_entry_fwd = 80 if S else (4 + 24 + 12)
+    # forward render: every list entry's data once per tile, the pixel outputs, and (recording forward) the 2-byte log
+    # record of every blended pair + n_contrib + tile flags
+    b["render_fwd"] = 8 * T + R * per_entry_fwd + N * (16 + (0 if mode_hier else 4)) + (2 * B + 4 * N + 4 * T if B else 0)
+    b["zero_fill"] = P * 64
+    if B:   # replay backward: the log, the blended entries' records (mean + id, conic/opacity, colour: 48 B), the pixel state,
             # and one read-modify-write of every visible Gaussian's 64-byte gradient record
-        b["render_bwd"] = 8 * T + 4 * B + R * (4 + 24 + 12) + N * (4 + 4 + 12 + 12) + 128 * P_v
+        b["render_bwd"] = 8 * T + 2 * B + R * 48 + N * (4 + 4 + 12 + 12) + 128 * P_v
     else:
         b["render_bwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (12 if S else 4)) + 128 * P_v
     b["bwd_preprocess"] = 4 * P + P_v * (64 + 36) + 4 * P + P_v * (36 + sh * (12 * M + 15) + 52) + P_v * (12 + sh * 12 * M + 28 + 28)
@@ -238,7 +242,7 @@ def main():
                 kname = "render_hier_replay_kernel" if (dom == "BwdRender" and recording) else \
                     f"render_kbuffer_kernel<{head}, {1 if dom == 'BwdRender' else (2 if recording else 0)}>"
         traffic = measured_traffic(kname, f"{args.workload}-{args.variant}")
-        fwd_bytes = sum(bts[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"))
+        fwd_bytes = sum(bts[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "gather", "render_fwd"))
         bwd_bytes = sum(bts[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess"))
         out = {
             "metric": "fwd+bwd frames/sec at 1920×1080, 1M Gaussians; PSNR vs reference",
