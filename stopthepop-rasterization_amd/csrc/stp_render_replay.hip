@@ -27,10 +27,6 @@ __device__ unsigned long long g_replay_stats[16];
 
 namespace {
 
-#ifndef STP_REPLAY_ABL
-#define STP_REPLAY_ABL 0 // timing experiments only (1: no eviction atomics, 2: no accumulation at all)
-#endif
-
 #ifndef STP_REPLAY_PREREDUCE
 #define STP_REPLAY_PREREDUCE 1 // DPP pre-reduction of quads / sub-tiles on one position: measured on C2, same-position lanes are
                                 // spread over the wave (55 blending lanes, 17.5 positions, 41.7 after a perfect per-quad merge): not worth its 50 instructions
@@ -232,10 +228,6 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
                 writer = writer && x == 0;
             }
         }
-#if STP_REPLAY_ABL == 2 // (timing experiment)
-        if (g[0] == 123.456f) atomicAdd(grad_slot(a, cur_id, 0), g[1] + g[2] + g[3] + g[4] + g[5] + g[6] + g[7] + g[8]);
-        continue;
-#endif
 #endif
 #ifdef STP_REPLAY_STATS
         {   // per wave-step: blending lanes, writer lanes after the pre-reductions, distinct positions among writers / blenders
