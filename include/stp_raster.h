@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 3
+#define STP_ABI_VERSION 4
 #define STP_GRAD_RECORD_FLOATS 16 /* floats per Gaussian in grad_records (see stp_backward) */
 
 /* Replaces CudaRasterizer::SplattingSettings + SortSettings + SortQueueSizes + CullingSettings
@@ -56,7 +56,15 @@ typedef struct StpSettings {
        (the re-sorting backward still handles tiles whose log overflowed).  Results are the same sums in a
        different order.  Set it for training forwards; leave it 0 for inference. */
     int32_t record_blend_log;
+    /* Replaces DebugVisualizationData::type (stopthepop/rasterizer_debug.h:11-21; rasterizer.h:203): 0 = disabled,
+       STP_DEBUG_DEPTH = the depth visualisation the Python flag `render_depth` selects (rasterize_points.cu:104-107):
+       the render kernels accumulate depth * alpha * T per pixel, the frame's minimum / maximum normalise it and the
+       Turbo colormap turns it into the output image (forward.cu:674-729).  Forward only. */
+    int32_t debug_visualization;
 } StpSettings;
+
+#define STP_DEBUG_DISABLED 0
+#define STP_DEBUG_DEPTH 1
 
 typedef enum StpStatus {
     STP_OK = 0,

@@ -22,7 +22,7 @@ class OrcSettings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "sort_mode", "sort_order", "queue_tile_4x4", "queue_tile_2x2", "queue_per_pixel",
         "rect_bounding", "tight_opacity_bounding", "tile_based_culling", "hierarchical_4x4_culling",
-        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1")]
+        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1", "debug_visualization")]
 
 
 def build(force: bool = False) -> str:
@@ -80,6 +80,7 @@ def settings_struct(d: Optional[dict] = None, tile_rows=None) -> OrcSettings:
     s.proper_ewa_scaling = int(bool(d.get("proper_ewa_scaling", False)))
     if tile_rows is not None:
         s.tile_y0, s.tile_y1 = int(tile_rows[0]), int(tile_rows[1])
+    s.debug_visualization = 1 if d.get("_render_depth") else 0  # private key: the reference's `render_depth` flag
     return s
 
 
@@ -183,8 +184,11 @@ def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, inv_viewprojmatri
     return Frame(handle, out, radii, rc, inputs)
 
 
-def forward_scene(scene, settings: Optional[dict] = None, tile_rows=None, use_cov3D_precomp: bool = False) -> Frame:
+def forward_scene(scene, settings: Optional[dict] = None, tile_rows=None, use_cov3D_precomp: bool = False,
+                  render_depth: bool = False) -> Frame:
     """Convenience: run the oracle on a diff_gaussian_rasterization.scenes.Scene."""
+    if render_depth:
+        settings = {**(settings or {}), "_render_depth": True}
     return forward(bg=scene.bg, means3D=scene.means3D, opacities=scene.opacities, viewmatrix=scene.viewmatrix,
                    projmatrix=scene.projmatrix, inv_viewprojmatrix=scene.inv_viewprojmatrix, campos=scene.campos,
                    tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, W=scene.W, H=scene.H, shs=scene.shs,

@@ -16,6 +16,7 @@
  * may differ by an ulp between host and device.
  */
 #include "stp_oracle.h"
+#include "../include/stp_turbo_colormap.h" // data table only
 
 #include <algorithm>
 #include <cfloat>
@@ -529,7 +530,16 @@ struct RenderCtx {
     const float* bg;
     const float* inv_vp;
     V3 cam;
+    bool debug_depth = false;      // DebugVisualization::Depth: the forward renders leave (sum depth*alpha*T, T) in channels 0, 1
+    const float* means3D = nullptr;
 };
+
+// ref: outputDebugVis, stopthepop_common.cuh:297-301
+inline void write_debug_depth(float* out, size_t N, size_t pid, float depth_acc, float T)
+{
+    out[pid] = depth_acc;
+    out[N + pid] = T;
+}
 
 // gradient accumulators (double, so the oracle's sums are order-independent to fp32 precision)
 struct GradAcc {
@@ -628,7 +638,7 @@ void render_global_fwd(OrcFrame& f, const RenderCtx& c, float* out)
             for (int lx = 0; lx < TILE; lx++) {
                 const int px = tx * TILE + lx, py = ty * TILE + ly;
                 if (px >= W || py >= H) continue;
-                float T = 1.0f, C[3] = {0, 0, 0};
+                float T = 1.0f, C[3] = {0, 0, 0}, depth_acc = 0.0f;
                 uint32_t contributor = 0, last = 0;
                 for (uint32_t k = r0; k < r1; k++) {
                     contributor++;
@@ -638,13 +648,18 @@ void render_global_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                     const float test_T = T * (1 - alpha);
                     if (test_T < T_THRESHOLD) break;
                     for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)id + ch] * alpha * T;
+                    if (c.debug_depth) { // ref: forward.cu:337-341: distance camera - mean, whatever the sort order
+                        const V3 d = {c.cam.x - c.means3D[3 * (size_t)id], c.cam.y - c.means3D[3 * (size_t)id + 1], c.cam.z - c.means3D[3 * (size_t)id + 2]};
+                        depth_acc += length3(d) * alpha * T;
+                    }
                     T = test_T;
                     last = contributor;
                 }
                 const size_t pid = (size_t)W * py + px;
                 f.final_T[pid] = T;
                 f.n_contrib[pid] = last;
-                for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
+                if (c.debug_depth) write_debug_depth(out, N, pid, depth_acc, T);
+                else for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
             }
     }
 }
@@ -766,7 +781,7 @@ void render_kbuffer(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, con
                 if (px >= W || py >= H) continue;
                 const V3 dir = view_ray(c.inv_vp, c.cam, {(float)px, (float)py}, W, H);
                 Window win; win.init(WIN);
-                float T = 1.0f, C[3] = {0, 0, 0};
+                float T = 1.0f, C[3] = {0, 0, 0}, depth_acc = 0.0f;
                 BwdPixel b;
                 if (BACKWARD) init_bwd_pixel(c, b, px, py, pixel_colors, dL_dpix);
                 bool done = false;
@@ -778,6 +793,7 @@ void render_kbuffer(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, con
                         const float test_T = T * (1 - a);
                         if (test_T < T_THRESHOLD) { win.num--; done = true; return; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)win.id[0] + ch] * a * T;
+                        if (c.debug_depth) depth_acc += win.depth[0] * a * T; // ref: resorted_render.cuh:107
                         T = test_T;
                     } else {
                         if (!blend_backward(c, *g, b, px, py, win.id[0], win.store[0])) { win.num--; done = true; return; }
@@ -801,7 +817,8 @@ void render_kbuffer(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, con
                     const size_t pid = (size_t)W * py + px;
                     f.final_T[pid] = T;
                     f.n_contrib[pid] = contributor;
-                    for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
+                    if (c.debug_depth) write_debug_depth(out, N, pid, depth_acc, T);
+                    else for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
                 }
             }
     }
@@ -864,7 +881,7 @@ struct HierPixel {
     int px = 0, py = 0;
     V3 dir{};
     Window head;
-    float T = 1.0f, C[3] = {0, 0, 0};
+    float T = 1.0f, C[3] = {0, 0, 0}, depth_acc = 0.0f;
     BwdPixel b{};
 };
 
@@ -889,6 +906,7 @@ struct HierSubTile {
             if (test_T < T_THRESHOLD) ok = false;
             else {
                 for (int ch = 0; ch < 3; ch++) p.C[ch] += c->feat[3 * (size_t)id + ch] * st * p.T;
+                if (c->debug_depth) p.depth_acc += p.head.depth[0] * st * p.T; // ref: :1005-1008
                 p.T = test_T;
                 ok = true;
             }
@@ -1052,7 +1070,8 @@ void render_hier(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, const 
                             if (!p.inside) continue;
                             const size_t pid = (size_t)W * p.py + p.px;
                             f.final_T[pid] = p.T;
-                            for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = p.C[ch] + p.T * c.bg[ch];
+                            if (c.debug_depth) write_debug_depth(out, N, pid, p.depth_acc, p.T);
+                            else for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = p.C[ch] + p.T * c.bg[ch];
                         }
             }
     }
@@ -1078,7 +1097,7 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                 const int px = tx * TILE + lx, py = ty * TILE + ly;
                 if (px >= W || py >= H) continue;
                 const V3 dir = view_ray(c.inv_vp, c.cam, {(float)px, (float)py}, W, H);
-                float T = 1.0f, C[3] = {0, 0, 0};
+                float T = 1.0f, C[3] = {0, 0, 0}, depth_acc = 0.0f;
                 bool done = false;
                 uint32_t contributor = 0, last_contributor = 0;
                 win.clear();
@@ -1105,6 +1124,7 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                         const float test_T = T * (1 - alpha);
                         if (test_T < T_THRESHOLD) { done = true; break; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)id + ch] * alpha * T;
+                        if (c.debug_depth) depth_acc += win[i].key * alpha * T; // ref: resorted_render.cuh:647
                         T = test_T;
                         last_contributor = contributor;
                     }
@@ -1116,8 +1136,34 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                 const size_t pid = (size_t)W * py + px;
                 f.final_T[pid] = T;
                 f.n_contrib[pid] = last_contributor;
-                for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
+                if (c.debug_depth) write_debug_depth(out, N, pid, depth_acc, T);
+                else for (int ch = 0; ch < 3; ch++) out[ch * N + pid] = C[ch] + T * c.bg[ch];
             }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DebugVisualization::Depth, second half.  ref: applyDebugVisualization (rasterizer_impl.cu:54-109: min and max of
+// channel 0 over the frame), render_debug_CUDA<DEPTH = true> (forward.cu:674-713) and colormapTurbo
+// (stopthepop_common.cuh:641-657).  Pixels of tiles outside a tile-row window keep their zeros, as on the device.
+// ------------------------------------------------------------------------------------------------
+static const float kTurbo[STP_TURBO_ENTRIES * 3] = STP_TURBO_TABLE_INITIALIZER;
+
+void apply_depth_colormap(float* out, size_t N)
+{
+    float mn = out[0], mx = out[0];
+    for (size_t i = 1; i < N; i++) { mn = std::min(mn, out[i]); mx = std::max(mx, out[i]); }
+    for (size_t i = 0; i < N; i++) {
+        const float T = out[N + i];
+        const float x = std::min(std::max(out[i] + T * mx, mn), mx) / (mx - mn);
+        const float interp = std::min(std::max(x * 255.0f, 0.0f), 255.0f);
+        const int lo = x > 0.0f ? (int)interp : 0;
+        const int hi = lo >= 255 ? 255 : lo + 1;
+        const float diff = interp - (float)lo;
+        for (int ch = 0; ch < 3; ch++) {
+            const float a = kTurbo[3 * lo + ch], b = kTurbo[3 * hi + ch];
+            out[ch * N + i] = std::min(std::max(a + (b - a) * diff, 0.0f), 1.0f);
+        }
     }
 }
 
@@ -1387,6 +1433,7 @@ int orc_forward(int P, int D, int M, const float* background, int W, int H, cons
     RenderCtx c;
     c.f = &f; c.feat = colors_precomp ? colors_precomp : f.rgb.data(); c.bg = background; c.inv_vp = inv_viewprojmatrix;
     c.cam = {cam_pos[0], cam_pos[1], cam_pos[2]};
+    c.debug_depth = f.s.debug_visualization == 1; c.means3D = means3D;
     switch (f.s.sort_mode) {
     case GLOBAL: render_global_fwd(f, c, out_color); break;
     case PPX_KBUFFER: render_kbuffer<false>(f, c, out_color, nullptr, nullptr, nullptr); break;
@@ -1394,6 +1441,7 @@ int orc_forward(int P, int D, int M, const float* background, int W, int H, cons
     case HIER: render_hier<false>(f, c, out_color, nullptr, nullptr, nullptr); break;
     default: if (frame_out) *frame_out = nullptr; delete fp; return -4;
     }
+    if (c.debug_depth) apply_depth_colormap(out_color, (size_t)W * H);
     const int R = f.R;
     if (!frame_out) delete fp;
     return R;

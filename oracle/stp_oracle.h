@@ -39,6 +39,9 @@ typedef struct OrcSettings {
        binned and rendered.  tile_y1 <= 0 means "all rows". */
     int32_t tile_y0;
     int32_t tile_y1;
+    /* 0 = normal image; 1 = DebugVisualization::Depth (what `render_depth=True` selects, ref: rasterize_points.cu:104-107):
+       sum(depth * alpha * T) per pixel, normalised by the frame's extrema, Turbo colormap (forward only) */
+    int32_t debug_visualization;
 } OrcSettings;
 
 typedef struct OrcFrame OrcFrame; /* opaque: forward state kept for backward / inspection */

@@ -125,6 +125,7 @@ ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* to
     s.final_T = c.take<float>(N, &off); note("final_T", off, N);
     s.n_contrib = c.take<uint32_t>(N, &off); note("n_contrib", off, N);
     s.ranges = c.take<uint2>(T, &off); note("ranges", off, 2 * T);
+    s.dbg_minmax = c.take<uint32_t>(2, &off); note("dbg_minmax", off, 2);
     if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 4 bytes per pixel
         s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
         s.blend_log = c.take<uint32_t>(T * 256 * 256 / 2, &off); note("blend_log", off, T * 256 * 256); // T x 4 waves x 256 records x 64 lanes, 2 B each
@@ -364,6 +365,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         return fail_hip(e, "render launch");
     }
     STP_DEBUG_SYNC("render");
+    STP_TRY(launch_render_debug_finish(f, img, out_color, st), "debug visualisation");
     g_timer.mark(4, st);
     return R;
 }

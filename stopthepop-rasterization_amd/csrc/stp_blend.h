@@ -38,6 +38,10 @@ struct RenderArgs {
     uint32_t* blend_log;   // (storage; the records are log_t)
     uint32_t* tile_flags;
     int flag_mode; // resorting backward: 0 = all tiles, 1 = only tiles with tile_flags != 0
+    // debug depth visualisation (StpSettings::debug_visualization == STP_DEBUG_DEPTH): the forward kernels write
+    // sum(depth * alpha * T) to channel 0 and T to channel 1 of out_color instead of the colour
+    int debug_depth;
+    const float* means3D; // GLOBAL mode's visualised depth is |cam - mean| (reference forward.cu:337-341)
 };
 
 // A log record is a 16-bit list position (measured on C2: 2-byte records cost the forward 0.05 ms less than 4-byte

@@ -17,7 +17,10 @@ constexpr size_t ALIGN = 256; // sub-array alignment inside the scratch buffers
 enum SortMode { MODE_GLOBAL = 0, MODE_FULL = 1, MODE_KBUFFER = 2, MODE_HIER = 3 };
 enum SortOrder { ORDER_Z = 0, ORDER_DISTANCE = 1, ORDER_PTD_CENTER = 2, ORDER_PTD_MAX = 3 };
 
-inline bool uses_blend_log(const StpSettings& s) { return s.record_blend_log != 0 && (s.sort_mode == MODE_HIER || s.sort_mode == MODE_KBUFFER); }
+inline bool uses_blend_log(const StpSettings& s)
+{
+    return s.record_blend_log != 0 && s.debug_visualization == 0 && (s.sort_mode == MODE_HIER || s.sort_mode == MODE_KBUFFER);
+}
 
 inline bool requires_depth_along_ray(const StpSettings& s) // reference rasterizer.h:66-71
 {
@@ -66,6 +69,7 @@ struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges 
     float* final_T;      // N
     uint32_t* n_contrib; // N
     uint2* ranges;       // T
+    uint32_t* dbg_minmax; // 2 (debug depth visualisation: the frame's extrema, as order-preserving integers)
     uint32_t* tile_flags; // T   (only with the blend log)
     uint32_t* blend_log;  // T * 4 waves * BLEND_LOG_DEPTH * 64 lanes (only with the blend log)
 };
@@ -141,6 +145,7 @@ hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const Imag
 hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st);
 hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
                                  float* out_color, hipStream_t st, std::string* err);
+hipError_t launch_render_debug_finish(const FrameParams& f, const ImageState& img, float* out_color, hipStream_t st);
 hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,
                                   const BackwardParams& bw, hipStream_t st, std::string* err);
 hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState& g, const int* radii, const BackwardParams& bw, hipStream_t st);

@@ -24,6 +24,11 @@ __device__ __forceinline__ uint32_t float_to_ordered(float f)
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
 
+__device__ __forceinline__ float ordered_to_float(uint32_t o)
+{
+    return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
+}
+
 __global__ void __launch_bounds__(256) render_full_fwd_kernel(const RenderArgs a)
 {
     __shared__ uint64_t s_key[1024];
@@ -58,7 +63,7 @@ __global__ void __launch_bounds__(256) render_full_fwd_kernel(const RenderArgs a
             };
             __syncthreads();
             for (int i = 0; i < 3; i++) s_key[256 * (i + 1) + tid] = make_key(i * 256 + tid); // slots 256..1023
-            float T = 1.0f, C[3] = {0, 0, 0};
+            float T = 1.0f, C[3] = {0, 0, 0}, depth_acc = 0.0f;
             uint32_t contributor = 0, last_contributor = 0;
             bool done = false;
             int todo = total;
@@ -110,6 +115,7 @@ __global__ void __launch_bounds__(256) render_full_fwd_kernel(const RenderArgs a
                         const float test_T = T * (1 - alpha);
                         if (test_T < T_THRESHOLD) { done = true; continue; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += s_col[ch][idx] * alpha * T;
+                        if (a.debug_depth) depth_acc += ordered_to_float((uint32_t)(s_key[idx] >> 32)) * alpha * T; // reference resorted_render.cuh:647
                         T = test_T;
                         last_contributor = contributor;
                     }
@@ -120,7 +126,8 @@ __global__ void __launch_bounds__(256) render_full_fwd_kernel(const RenderArgs a
                 const size_t pid = (size_t)a.W * py + px;
                 a.final_T[pid] = T;
                 a.n_contrib[pid] = last_contributor;
-                for (int ch = 0; ch < 3; ch++) a.out_color[ch * N + pid] = C[ch] + T * a.bg[ch];
+                if (a.debug_depth) { a.out_color[pid] = depth_acc; a.out_color[N + pid] = T; }
+                else for (int ch = 0; ch < 3; ch++) a.out_color[ch * N + pid] = C[ch] + T * a.bg[ch];
             }
         }
 }

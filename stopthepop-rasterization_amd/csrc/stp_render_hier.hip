@@ -12,7 +12,10 @@ namespace stp {
 STP_DECL(launch_hier_fwd_mid8);
 STP_DECL(launch_hier_bwd_mid8);
 STP_DECL(launch_hier_rec_mid8);
+STP_DECL(launch_hier_dbg_mid8);
 #ifndef STP_FASTBUILD
+STP_DECL(launch_hier_dbg_mid12);
+STP_DECL(launch_hier_dbg_mid20);
 STP_DECL(launch_hier_fwd_mid12);
 STP_DECL(launch_hier_fwd_mid20);
 STP_DECL(launch_hier_bwd_mid12);
@@ -22,14 +25,15 @@ STP_DECL(launch_hier_rec_mid20);
 #endif
 #undef STP_DECL
 
-// mode: 0 forward, 1 resorting backward, 2 recording forward
+// mode: 0 forward, 1 resorting backward, 2 recording forward, 3 forward of the debug depth visualisation
 static hipError_t dispatch(int mode, const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err)
 {
     const bool backward = mode == 1;
     const int head = f.s.queue_per_pixel, mid = f.s.queue_tile_2x2;
     bool handled = false, mid_ok = false;
     hipError_t e = hipErrorInvalidValue;
-#define STP_PICK(M) (mode == 1 ? launch_hier_bwd_mid##M(f, a, st, &handled) : mode == 2 ? launch_hier_rec_mid##M(f, a, st, &handled) : launch_hier_fwd_mid##M(f, a, st, &handled))
+#define STP_PICK(M) (mode == 1 ? launch_hier_bwd_mid##M(f, a, st, &handled) : mode == 2 ? launch_hier_rec_mid##M(f, a, st, &handled) : \
+                     mode == 3 ? launch_hier_dbg_mid##M(f, a, st, &handled) : launch_hier_fwd_mid##M(f, a, st, &handled))
     if (mid == 8) { mid_ok = true; e = STP_PICK(8); }
 #ifndef STP_FASTBUILD
     else if (mid == 12) { mid_ok = true; e = STP_PICK(12); }
@@ -47,5 +51,6 @@ static hipError_t dispatch(int mode, const FrameParams& f, const RenderArgs& a, 
 hipError_t launch_hier_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err) { return dispatch(0, f, a, st, err); }
 hipError_t launch_hier_bwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err) { return dispatch(1, f, a, st, err); }
 hipError_t launch_hier_rec(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err) { return dispatch(2, f, a, st, err); }
+hipError_t launch_hier_dbg(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err) { return dispatch(3, f, a, st, err); }
 
 } // namespace stp

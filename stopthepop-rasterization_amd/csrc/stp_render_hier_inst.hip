@@ -1,6 +1,6 @@
 // stp_render_hier_inst.hip -- one slice of the hierarchical kernel's instantiation ladder.
 // Compiled several times by the Makefile with -DSTP_INST_MID={8,12,20} -DSTP_INST_MODE={0,1,2}
-// (0 forward, 1 resorting backward, 2 recording forward), so the
+// (0 forward, 1 resorting backward, 2 recording forward, 3 depth-visualisation forward), so the
 // template instantiations (HEAD x CULL per slice) build in parallel.  Queue-size ladders follow the
 // reference: forward HEAD in {4,8,16} (forward.cu:465-472), backward HEAD in {4,8,12,16}
 // (backward.cu:745-752), MID in {8,12,20}.  -DSTP_FASTBUILD keeps only HEAD 4 (with MID 8), the
@@ -20,6 +20,8 @@
 #define STP_FN STP_CAT(launch_hier_bwd_mid, STP_INST_MID)
 #elif STP_INST_MODE == 2
 #define STP_FN STP_CAT(launch_hier_rec_mid, STP_INST_MID)
+#elif STP_INST_MODE == 3
+#define STP_FN STP_CAT(launch_hier_dbg_mid, STP_INST_MID)
 #else
 #define STP_FN STP_CAT(launch_hier_fwd_mid, STP_INST_MID)
 #endif

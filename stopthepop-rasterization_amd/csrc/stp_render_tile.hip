@@ -75,6 +75,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
     __shared__ float2 s_xy[BLOCK];
     __shared__ float4 s_co[BLOCK];
     __shared__ float s_col[3][BLOCK];
+    __shared__ float s_dist[BLOCK]; // debug depth visualisation only: |cam - mean| of the staged entries
 
     const TileCtx c = tile_ctx(a);
     const float pxf = (float)c.px, pyf = (float)c.py;
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
     const int rounds = (total + BLOCK - 1) / BLOCK;
     int todo = total;
 
-    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    float T = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f, depth_acc = 0.0f;
     uint32_t contributor = 0, last_contributor = 0;
 
     for (int i = 0; i < rounds; i++, todo -= BLOCK) {
@@ -96,6 +97,10 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
             s_col[0][threadIdx.x] = a.features[3 * (size_t)id + 0];
             s_col[1][threadIdx.x] = a.features[3 * (size_t)id + 1];
             s_col[2][threadIdx.x] = a.features[3 * (size_t)id + 2];
+            if (a.debug_depth) { // reference forward.cu:337-341
+                const float ddx = a.cam[0] - a.means3D[3 * (size_t)id], ddy = a.cam[1] - a.means3D[3 * (size_t)id + 1], ddz = a.cam[2] - a.means3D[3 * (size_t)id + 2];
+                s_dist[threadIdx.x] = sqrtf(ddx * ddx + ddy * ddy + ddz * ddz);
+            }
         }
         __syncthreads();
         const int n = min(BLOCK, todo);
@@ -113,6 +118,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
             C0 += s_col[0][j] * alpha * T;
             C1 += s_col[1][j] * alpha * T;
             C2 += s_col[2][j] * alpha * T;
+            if (a.debug_depth) depth_acc += s_dist[j] * alpha * T;
             T = test_T;
             last_contributor = contributor;
         }
@@ -121,9 +127,14 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
         const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * c.py + c.px;
         a.final_T[pid] = T;
         a.n_contrib[pid] = last_contributor;
-        a.out_color[pid] = C0 + T * a.bg[0];
-        a.out_color[N + pid] = C1 + T * a.bg[1];
-        a.out_color[2 * N + pid] = C2 + T * a.bg[2];
+        if (a.debug_depth) { // reference outputDebugVis, stopthepop_common.cuh:297-301
+            a.out_color[pid] = depth_acc;
+            a.out_color[N + pid] = T;
+        } else {
+            a.out_color[pid] = C0 + T * a.bg[0];
+            a.out_color[N + pid] = C1 + T * a.bg[1];
+            a.out_color[2 * N + pid] = C2 + T * a.bg[2];
+        }
     }
 }
 
@@ -239,13 +250,14 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
 // MODE 0 = forward, 1 = backward that re-runs the window sort (the reference's scheme; nine atomics per blended pair),
 // 2 = training forward: additionally records every pixel's blend order in the blend log, so that the backward is the
 // replay kernel of stp_render_replay.hip (the same log format and thread -> pixel mapping as the hierarchical mode).
-constexpr int KB_FWD = 0, KB_BWD = 1, KB_FWD_RECORD = 2;
+constexpr int KB_FWD = 0, KB_BWD = 1, KB_FWD_RECORD = 2, KB_FWD_DEPTH = 3; // 3: forward of the debug depth visualisation
 
 template <int WIN, int MODE>
 __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs a)
 {
     constexpr bool BACKWARD = MODE == KB_BWD;
     constexpr bool RECORD = MODE == KB_FWD_RECORD;
+    constexpr bool DEPTHVIZ = MODE == KB_FWD_DEPTH;
     // one staging round = BLOCK entry records (A, B, C, D of BinningState), read with unit stride from the list-ordered
     // entry arrays; the forward passes carry the list position through the window, the backward pass the Gaussian id
     __shared__ float4 s_A[BLOCK];
@@ -281,6 +293,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     if constexpr (BACKWARD) init_bwd_pixel(bp, a, c.inside, c.px, c.py);
     else init_fwd_pixel(fp);
     uint32_t contributor = 0;
+    float depth_acc = 0.0f;
     log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(a.blend_log) + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
     int nrec = 0;
     const float4* const eF = a.entF + c.range.x;
@@ -293,7 +306,9 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             const int pos = win.id[0];
             const float4 colr = eF[pos];
             const float col[3] = {colr.x, colr.y, colr.z};
+            const float T_before = fp.T;
             ok = blend_forward_c(fp, col, win.store[0]);
+            if constexpr (DEPTHVIZ) { if (ok) depth_acc += win.depth[0] * win.store[0] * T_before; } // reference resorted_render.cuh:107
             if constexpr (RECORD) {
                 if (ok) {
                     if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (log_t)pos;
@@ -342,9 +357,14 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * c.py + c.px;
             a.final_T[pid] = fp.T;
             a.n_contrib[pid] = RECORD ? (uint32_t)nrec : contributor; // (recording forward: the pixel's number of log records)
-            a.out_color[pid] = fp.C[0] + fp.T * a.bg[0];
-            a.out_color[N + pid] = fp.C[1] + fp.T * a.bg[1];
-            a.out_color[2 * N + pid] = fp.C[2] + fp.T * a.bg[2];
+            if constexpr (DEPTHVIZ) {
+                a.out_color[pid] = depth_acc;
+                a.out_color[N + pid] = fp.T;
+            } else {
+                a.out_color[pid] = fp.C[0] + fp.T * a.bg[0];
+                a.out_color[N + pid] = fp.C[1] + fp.T * a.bg[1];
+                a.out_color[2 * N + pid] = fp.C[2] + fp.T * a.bg[2];
+            }
         }
         if constexpr (RECORD) {
             if (nrec > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
@@ -364,6 +384,7 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     a.final_T = img.final_T; a.n_contrib = img.n_contrib;
     a.blend_log = img.blend_log; a.tile_flags = img.tile_flags; a.flag_mode = 0;
+    a.debug_depth = f.s.debug_visualization == STP_DEBUG_DEPTH ? 1 : 0; a.means3D = f.means3D;
     return a;
 }
 
@@ -371,6 +392,8 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
 hipError_t launch_hier_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
 hipError_t launch_hier_bwd(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
 hipError_t launch_hier_rec(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
+hipError_t launch_hier_dbg(const FrameParams& f, const RenderArgs& a, hipStream_t st, std::string* err);
+hipError_t launch_depth_colormap(float* out_color, int N, uint32_t* minmax, hipStream_t st); // stp_debug_viz.hip
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 hipError_t launch_full_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 
@@ -402,11 +425,24 @@ hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, c
     case MODE_GLOBAL:
         hipLaunchKernelGGL(render_global_fwd_kernel, grid, block, 0, st, a);
         return hipGetLastError();
-    case MODE_KBUFFER: return uses_blend_log(f.s) ? launch_kbuffer<KB_FWD_RECORD>(f, a, st) : launch_kbuffer<KB_FWD>(f, a, st);
+    case MODE_KBUFFER:
+        if (a.debug_depth) return launch_kbuffer<KB_FWD_DEPTH>(f, a, st);
+        return uses_blend_log(f.s) ? launch_kbuffer<KB_FWD_RECORD>(f, a, st) : launch_kbuffer<KB_FWD>(f, a, st);
     case MODE_FULL: return launch_full_fwd(f, a, st);
-    case MODE_HIER: return uses_blend_log(f.s) ? launch_hier_rec(f, a, st, err) : launch_hier_fwd(f, a, st, err);
+    case MODE_HIER:
+        if (a.debug_depth) return launch_hier_dbg(f, a, st, err);
+        return uses_blend_log(f.s) ? launch_hier_rec(f, a, st, err) : launch_hier_fwd(f, a, st, err);
     default: if (err) *err = "invalid sort mode"; return hipErrorInvalidValue;
     }
+}
+
+// The forward of the debug depth visualisation: the render kernels above leave sum(depth * alpha * T) in channel 0 and T
+// in channel 1; the frame's extrema and the colormap finish the image (reference applyDebugVisualization,
+// rasterizer_impl.cu:54-109).
+hipError_t launch_render_debug_finish(const FrameParams& f, const ImageState& img, float* out_color, hipStream_t st)
+{
+    if (f.s.debug_visualization != STP_DEBUG_DEPTH) return hipSuccess;
+    return launch_depth_colormap(out_color, f.W * f.H, img.dbg_minmax, st);
 }
 
 hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,

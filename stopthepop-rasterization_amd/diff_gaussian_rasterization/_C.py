@@ -29,7 +29,7 @@ class StpSettings(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "sort_mode", "sort_order", "queue_tile_4x4", "queue_tile_2x2", "queue_per_pixel",
         "rect_bounding", "tight_opacity_bounding", "tile_based_culling", "hierarchical_4x4_culling",
-        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1", "record_blend_log")]
+        "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1", "record_blend_log", "debug_visualization")]
 
 
 _ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
@@ -76,7 +76,7 @@ def _load():
     L.stp_timing_enable.restype = None
     L.stp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.stp_timing_read.restype = ci
-    if L.stp_abi_version() != 3:
+    if L.stp_abi_version() != 4:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L
     return L
@@ -218,8 +218,6 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D)
-    if render_depth:
-        raise NotImplementedError("render_depth (debug depth visualisation) is outside the accelerated hot path")
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
     out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
@@ -229,6 +227,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if P != 0:
         M = int(sh.size(1)) if sh.numel() != 0 else 0
         s = settings_from_dict(settings_dict)
+        if render_depth:  # DebugVisualization::Depth (reference rasterize_points.cu:104-107); no log: it has no backward
+            s.debug_visualization = 1
+            s.record_blend_log = 0
         t = [_prep(x, dev) for x in (background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp,
                                      viewmatrix, projmatrix, inv_viewprojmatrix, campos)]
         bg_, m3_, sh_, col_, op_, sc_, ro_, c3_, vm_, pm_, inv_, cam_ = t

@@ -36,7 +36,7 @@ def ext_settings(d):
 class GpuRun:
     """Runs one scene through the product's public API on cuda:0 and keeps what the tests inspect."""
 
-    def __init__(self, scene, sdict, backward=True, device="cuda:0", tile_rows=None, debug=False):
+    def __init__(self, scene, sdict, backward=True, device="cuda:0", tile_rows=None, debug=False, render_depth=False):
         import torch
         import diff_gaussian_rasterization as dgr
         from diff_gaussian_rasterization import _C
@@ -56,7 +56,7 @@ class GpuRun:
             image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
             scale_modifier=scene.scale_modifier, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix),
             inv_viewprojmatrix=t(scene.inv_viewprojmatrix), sh_degree=scene.sh_degree, campos=t(scene.campos),
-            prefiltered=False, settings=es, render_depth=False, debug=debug)
+            prefiltered=False, settings=es, render_depth=render_depth, debug=debug)
         self.rs = rs
         rast = dgr.GaussianRasterizer(rs)
         color, radii = rast(self.means3D, self.means2D, self.opac, shs=self.shs, colors_precomp=self.colors,
@@ -75,7 +75,7 @@ class GpuRun:
             out = _C.rasterize_gaussians(rs.bg, self.means3D, e(self.colors), self.opac, self.scales, self.rots, rs.scale_modifier,
                                          empty, rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy,
                                          rs.image_height, rs.image_width, e(self.shs), rs.sh_degree, rs.campos, False,
-                                         es.to_dict(), False, debug)
+                                         es.to_dict(), render_depth, debug)
             self.num_rendered, color2 = out[0], out[1]
             assert torch.equal(color2, color)
             self.geom, self.binning, self.img = out[3], out[4], out[5]
@@ -100,8 +100,8 @@ class GpuRun:
         return self._C.image_array(self.img, self.scene.W, self.scene.H, name).cpu().numpy()
 
 
-def oracle_run(scene, sdict, backward=True, tile_rows=None):
+def oracle_run(scene, sdict, backward=True, tile_rows=None, render_depth=False):
     from oracle import oracle as orc
-    f = orc.forward_scene(scene, sdict, tile_rows=tile_rows)
+    f = orc.forward_scene(scene, sdict, tile_rows=tile_rows, render_depth=render_depth)
     g = f.backward(scene.dL_dout) if backward else None
     return f, g

@@ -108,7 +108,7 @@ def test_c_abi_exports_every_declared_symbol():
 
 def test_c_abi_size_and_layout_queries_without_gpu():
     L = _C._load()
-    assert L.stp_abi_version() == 3
+    assert L.stp_abi_version() == 4
     s = _C.settings_from_dict(dgr.ExtendedSettings().to_dict())
     small, big = L.stp_geometry_buffer_size(1000, ctypes.byref(s)), L.stp_geometry_buffer_size(2000, ctypes.byref(s))
     assert 0 < small < big

@@ -167,6 +167,24 @@ def test_sh_degrees_and_coefficient_counts(degree, M):
     assert not np.any(g.grads["dL_dsh"][:, (degree + 1) ** 2:, :])  # nothing flows into inactive coefficients
 
 
+@pytest.mark.parametrize("sd", [settings_dict(0), settings_dict(0, order=1), settings_dict(2, per_pixel=16), settings_dict(1),
+                                settings_dict(3), settings_dict(**FULL_STP), settings_dict(3, per_pixel=8, tile_2x2=12, h44=True)],
+                         ids=["global_z", "global_dist", "kbuffer16", "ppx_full", "hier", "full_stp", "hier_8_12"])
+def test_render_depth_visualisation(sd):
+    """`render_depth=True` (reference rasterize_points.cu:104-107): sum(depth * alpha * T) per pixel, normalised by the
+    frame's extrema, Turbo colormap -- in every sort mode, against the oracle."""
+    # (a sparse scene: uncovered pixels put the frame minimum at 0, otherwise the reference's normalisation
+    # clamp(v, min, max) / (max - min) saturates almost everywhere)
+    sc = scenes.make_scene(P=800, W=80, H=64, sigma_min=2.0, sigma_max=8.0, seed=9, camera="orbit", opacity_range=(0.5, 0.95))
+    g = GpuRun(sc, sd, backward=False, render_depth=True)
+    f, _ = oracle_run(sc, sd, backward=False, render_depth=True)
+    assert g.color.shape == (3, sc.H, sc.W) and g.color.min() >= 0.0 and g.color.max() <= 1.0
+    assert np.ptp(f.color) > 0.5  # the test image really spans the colormap
+    assert max_abs(g.color, f.color) <= 2e-4  # the colormap's slope multiplies the 1e-6 of the accumulated depth
+    # the ordinary image of the same scene is unaffected by the flag's plumbing
+    assert np.array_equal(GpuRun(sc, sd, backward=False).color, GpuRun(sc, sd, backward=False, render_depth=False).color)
+
+
 # ---- blend log (training forward records the blend order, backward replays it) ----
 HAZE = dict(P=3000, W=48, H=48, sigma_min=10.0, sigma_max=20.0, seed=21, opacity_range=(0.01, 0.03))
 

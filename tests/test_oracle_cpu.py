@@ -161,3 +161,18 @@ def test_golden_fixtures(name):
     assert max_abs(ref["color"], out["color"]) < 1e-6
     for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales"):
         assert _rel(out[k], ref[k]) < 1e-5
+
+
+def test_render_depth_visualisation_oracle():
+    """DebugVisualization::Depth (`render_depth=True`): an RGB image from the Turbo table, identical for the exact
+    per-pixel sorts at low density, and with the frame's uncovered pixels at the top of the colormap."""
+    sc = scenes.make_scene(P=25, W=64, H=48, sigma_min=1.5, sigma_max=4.0, seed=17, opacity_range=(0.5, 0.95))
+    imgs = {m: orc.forward_scene(sc, settings_dict(m, per_pixel=16), render_depth=True).color for m in (0, 1, 2, 3)}
+    for img in imgs.values():
+        assert img.shape == (3, sc.H, sc.W) and img.min() >= 0.0 and img.max() <= 1.0
+    assert np.array_equal(imgs[1], imgs[2])              # PPX_FULL == k-buffer(16) here
+    assert np.max(np.abs(imgs[3] - imgs[1])) < 1e-4       # hierarchical: same order, another summation path
+    empty = orc.forward_scene(sc, settings_dict(1)).array("final_T").reshape(sc.H, sc.W) == 1.0
+    assert empty.any()
+    top = np.array([0.47960, 0.01583, 0.01055], np.float32).reshape(3, 1)  # last entry of the Turbo table
+    assert np.allclose(imgs[1][:, empty], top, atol=1e-6)
