@@ -27,9 +27,8 @@ __device__ unsigned long long g_replay_stats[16];
 
 namespace {
 
-#ifndef STP_REPLAY_PREREDUCE
-#define STP_REPLAY_PREREDUCE 1 // DPP pre-reduction of quads / sub-tiles on one position: measured on C2, same-position lanes are
-                                // spread over the wave (55 blending lanes, 17.5 positions, 41.7 after a perfect per-quad merge): not worth its 50 instructions
+#ifndef STP_REPLAY_PAIRMERGE
+#define STP_REPLAY_PAIRMERGE 2 // merge levels: 1 = inside 2x2 quads, 2 = + 8-lane halves (best on C2: 0.965 ms vs 0.995 / 0.987), 3 = + 16-lane rows
 #endif
 
 #ifndef STP_REPLAY_RW
@@ -176,6 +175,34 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
             ok = blend_backward_terms(bp, a, px, py, cur_fd, G, g);
             if (!ok) n = k; // (an ulp of difference against the forward's transmittance: stop where it says so)
         }
+#if STP_REPLAY_PAIRMERGE
+        // Pairwise merge (DPP): a lane and its partner -- lane^1, lane^2, then the mirror lane of its 8-lane half -- that
+        // hold the same list position sum their terms in registers and only one of them goes to LDS.  Per step 55 lanes
+        // blend on 17.5 distinct positions (C2); the LDS atomics are the limiter and serialise on equal addresses, the
+        // VALU has headroom: C2-full 1.38 -> 0.97 ms.  (A pre-reduction that needs a whole quad on one position fires
+        // for one quad in ten and does not pay.)
+        {
+            int key = ok ? cur_pos : -2 - lane; // unique when not blending
+#define STP_MERGE_LEVEL(CTRL, LOWER)                                                                                    \
+            {                                                                                                       \
+                const int pk = __builtin_amdgcn_mov_dpp(key, CTRL, 0xF, 0xF, true);                                 \
+                const bool match = pk == key;                                                                       \
+                const float mf = (match && (LOWER)) ? 1.0f : 0.0f;                                                  \
+                _Pragma("unroll") for (int kk = 0; kk < 9; kk++)                                                    \
+                    g[kk] = fmaf(__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g[kk]), CTRL, 0xF, 0xF, true)), mf, g[kk]); \
+                if (match && !(LOWER)) { ok = false; key = -2 - lane; }                                             \
+            }
+            STP_MERGE_LEVEL(0xB1, (q & 1) == 0) // partner lane ^ 1 (quad_perm [1,0,3,2])
+            STP_MERGE_LEVEL(0x4E, (q & 2) == 0) // partner lane ^ 2 (quad_perm [2,3,0,1])
+#if STP_REPLAY_PAIRMERGE >= 2
+            STP_MERGE_LEVEL(0x141, (x & 7) < 4)  // partner 7 - i inside each 8-lane half (row_half_mirror)
+#endif
+#if STP_REPLAY_PAIRMERGE >= 3
+            STP_MERGE_LEVEL(0x140, x < 8)        // partner 15 - i inside the 16-lane row (row_mirror)
+#endif
+#undef STP_MERGE_LEVEL
+        }
+#endif
         if (direct) { // every list position has its own sums in LDS: nine adds, nothing else
             if (ok) {
                 float gmax = fabsf(g[0]);
@@ -195,40 +222,9 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
             }
             continue;
         }
-        // ---- accumulate (converged code: every lane of the wave is here) ----
-        // Neighbouring pixels blend the same entry at the same step more often than not: sum the terms of a
-        // 2x2 quad (and then of a whole 4x4 sub-tile) with DPP when all its lanes hold the same list position,
-        // so that one lane goes to LDS instead of 4 (16) lanes hitting the same address.
+        // ---- accumulate through the per-wave cache (converged code: every lane of the wave is here) ----
         const int key = ok ? cur_pos : -2 - lane; // unique when not blending
         bool writer = ok;
-#if STP_REPLAY_PREREDUCE
-        {
-            const int k0 = quad_bcast_i<0>(key), k1 = quad_bcast_i<1>(key), k2 = quad_bcast_i<2>(key), k3 = quad_bcast_i<3>(key);
-            const bool quad_same = (k0 == k1) && (k0 == k2) && (k0 == k3);
-            if (quad_same) {
-#pragma unroll
-                for (int kk = 0; kk < 9; kk++) {
-                    g[kk] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g[kk]), 0xB1, 0xF, 0xF, true)); // quad_perm [1,0,3,2]
-                    g[kk] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g[kk]), 0x4E, 0xF, 0xF, true)); // quad_perm [2,3,0,1]
-                }
-                writer = writer && q == 0;
-            }
-            // whole sub-tile (16-lane row) on one position: its four quad sums are combined with two more DPP steps
-            const unsigned long long qs = __ballot(quad_same);
-            const int r0 = __builtin_amdgcn_mov_dpp(key, 0x140, 0xF, 0xF, true);  // row_mirror: lane i <- 15 - i
-            const int r1 = __builtin_amdgcn_mov_dpp(key, 0x141, 0xF, 0xF, true);  // row_half_mirror: lane i <- 7 - i (per half)
-            const bool row_quads = ((qs >> (lane & ~15)) & 0xFFFFull) == 0xFFFFull;
-            const unsigned long long rm = __ballot(row_quads && key == r0 && key == r1);
-            if (((rm >> (lane & ~15)) & 0xFFFFull) == 0xFFFFull) {
-#pragma unroll
-                for (int kk = 0; kk < 9; kk++) {
-                    g[kk] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g[kk]), 0x141, 0xF, 0xF, true));
-                    g[kk] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g[kk]), 0x140, 0xF, 0xF, true));
-                }
-                writer = writer && x == 0;
-            }
-        }
-#endif
 #ifdef STP_REPLAY_STATS
         {   // per wave-step: blending lanes, writer lanes after the pre-reductions, distinct positions among writers / blenders
             int first_w = writer ? 1 : 0, first_b = ok ? 1 : 0, first_q = ok ? 1 : 0, first_r = ok ? 1 : 0;
