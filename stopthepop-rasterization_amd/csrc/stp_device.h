@@ -87,6 +87,17 @@ template <int I> __device__ __forceinline__ float quad_fma(float a, float b, flo
     return acc;
 }
 
+// acc += partner(a) * b in one instruction, the partner lane given by a DPP control: 0xB1 = lane ^ 1, 0x4E = lane ^ 2
+// (quad_perm), 0x141 = mirror inside the 8-lane half, 0x140 = mirror inside the 16-lane row.  Same caveats as above.
+template <int CTRL> __device__ __forceinline__ float partner_fma(float a, float b, float acc)
+{
+    if constexpr (CTRL == 0xB1) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (CTRL == 0x4E) asm("v_fmac_f32_dpp %0, %1, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    else if constexpr (CTRL == 0x141) asm("v_fmac_f32_dpp %0, %1, %2 row_half_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    else asm("v_fmac_f32_dpp %0, %1, %2 row_mirror row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(a), "v"(b));
+    return acc;
+}
+
 struct Mat3 { float m[3][3]; }; // m[c][r]: column c, row r (same storage convention as the reference's vector library)
 
 __device__ __forceinline__ Mat3 mat_mul(const Mat3& a, const Mat3& b)

@@ -28,7 +28,8 @@ __device__ unsigned long long g_replay_stats[16];
 namespace {
 
 #ifndef STP_REPLAY_PAIRMERGE
-#define STP_REPLAY_PAIRMERGE 2 // merge levels: 1 = inside 2x2 quads, 2 = + 8-lane halves (best on C2: 0.965 ms vs 0.995 / 0.987), 3 = + 16-lane rows
+#define STP_REPLAY_PAIRMERGE 3 // merge levels: 1 = inside 2x2 quads (lane^1, lane^2), 2 = + mirror in the 8-lane half, 3 = + mirror in the 16-lane row
+                               // (C2-full: 1.38 ms without, 0.99 / 0.95 / 0.94 ms with 1 / 2 / 3)
 #endif
 
 #ifndef STP_REPLAY_RW
@@ -176,10 +177,10 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
             if (!ok) n = k; // (an ulp of difference against the forward's transmittance: stop where it says so)
         }
 #if STP_REPLAY_PAIRMERGE
-        // Pairwise merge (DPP): a lane and its partner -- lane^1, lane^2, then the mirror lane of its 8-lane half -- that
+        // Pairwise merge (DPP): a lane and its partner -- lane^1, lane^2, then the mirror lanes of its 8-lane half and row -- that
         // hold the same list position sum their terms in registers and only one of them goes to LDS.  Per step 55 lanes
         // blend on 17.5 distinct positions (C2); the LDS atomics are the limiter and serialise on equal addresses, the
-        // VALU has headroom: C2-full 1.38 -> 0.97 ms.  (A pre-reduction that needs a whole quad on one position fires
+        // VALU has headroom: C2-full 1.38 -> 0.94 ms.  The partner's value enters as the DPP operand of one v_fmac per term.  (A pre-reduction that needs a whole quad on one position fires
         // for one quad in ten and does not pay.)
         {
             int key = ok ? cur_pos : -2 - lane; // unique when not blending
@@ -188,8 +189,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_hier_replay_kernel
                 const int pk = __builtin_amdgcn_mov_dpp(key, CTRL, 0xF, 0xF, true);                                 \
                 const bool match = pk == key;                                                                       \
                 const float mf = (match && (LOWER)) ? 1.0f : 0.0f;                                                  \
-                _Pragma("unroll") for (int kk = 0; kk < 9; kk++)                                                    \
-                    g[kk] = fmaf(__int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(g[kk]), CTRL, 0xF, 0xF, true)), mf, g[kk]); \
+                dpp_hazard_guard(); /* g[] was written by ordinary VALU instructions a moment ago */                \
+                _Pragma("unroll") for (int kk = 0; kk < 9; kk++) g[kk] = partner_fma<CTRL>(g[kk], mf, g[kk]);       \
                 if (match && !(LOWER)) { ok = false; key = -2 - lane; }                                             \
             }
             STP_MERGE_LEVEL(0xB1, (q & 1) == 0) // partner lane ^ 1 (quad_perm [1,0,3,2])
