@@ -10,10 +10,11 @@ rect/tight/tile-based/4x4 culling + load balancing, `--variant min` = plain Z or
 resident in HBM, through the public drop-in API (GaussianRasterizer -> autograd -> _C -> C ABI).
 Rank 0 prints ONE JSON line (contract in the task statement / DESIGN.md section "Measurement").
 
-N > 1 (default `--shard tilerows`): the frame is partitioned by screen-tile row; every rank renders its
-rows, the image strips are gathered to rank 0 over RCCL, the per-Gaussian partial gradients are
-all-reduced (strong scaling: the work per step is one frame regardless of N).  `--shard frames` runs N
-independent frames instead (weak scaling).
+N > 1: the unit of the metric is a frame, and frames are independent, so the headline shards FRAMES over the ranks
+(`--shard frames`, the default): every rank renders its own frame, no data-path collective, weak scaling.  The same
+run then also times the north star's optional mode -- ONE frame partitioned by screen-tile row, image strips gathered
+to rank 0 over RCCL, per-Gaussian gradient records all-reduced (strong scaling) -- and reports it in the `tile_shard`
+object of the JSON line.  `--shard tilerows` makes that mode the headline instead.
 
 The `cpu_baseline` leg (rank 0, N == 1 only) times the CPU oracle on a bounded sample of the same frame:
 it is a reported, non-target baseline.
@@ -105,7 +106,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--variant", default="full", choices=["full", "min"])
-    ap.add_argument("--shard", default="tilerows", choices=["tilerows", "frames"])
+    ap.add_argument("--shard", default="frames", choices=["tilerows", "frames"])
+    ap.add_argument("--no-tile-shard-probe", action="store_true", help="N > 1: skip the auxiliary tile-row-shard timing")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalidates the headline number)")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -205,6 +207,38 @@ def main():
     value = frames_per_step * args.steps / dt
     ms_per_step = 1000.0 * dt / args.steps
 
+    # auxiliary measurement (N > 1, or --force-shard handled above): one frame sharded by tile row over all ranks
+    tile_probe = None
+    if world > 1 and not sharded and not args.no_tile_shard_probe:
+        try:
+            r2 = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
+
+            def step2():
+                for x in leaves:
+                    if x is not None and x.grad is not None:
+                        x.grad = None
+                color, _ = r2(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+                if not fwd_only:
+                    (color * w_img).sum().backward()
+
+            k2 = max(1, min(args.steps, 10))
+            for _ in range(2):
+                step2()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                step2()
+            barrier()
+            dt2 = time.perf_counter() - t2
+            tt2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+            dt2 = float(tt2.item())
+            tile_probe = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
+                          "scaling": "strong", "parallelism": f"tilerows{world}",
+                          "exchange": "gather of image strips to rank 0 + all-reduce of 36 B per Gaussian (RCCL)"}
+        except Exception as ex:  # the headline above stands on its own
+            tile_probe = {"error": repr(ex)[:300]}
+
     if rank == 0:
         # measured sizes for the byte model
         radii = state["radii"]
@@ -263,6 +297,8 @@ def main():
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
                          "whole_step_frac": round(((fwd_bytes + (0 if fwd_only else bwd_bytes)) / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)},
         }
+        if tile_probe is not None:
+            out["tile_shard"] = tile_probe
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sdict, gy, fwd_only, args.cpu_rows)
         print(json.dumps(out), flush=True)
