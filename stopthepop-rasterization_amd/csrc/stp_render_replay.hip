@@ -1,4 +1,4 @@
-// stp_render_replay.hip -- backward of the hierarchical mode by REPLAYING the forward's blend log.
+// stp_render_replay.hip -- backward of the per-pixel-sort modes by REPLAYING the forward's blend log.
 //
 // No counterpart in the reference: its backward (hierarchical_render.cuh:1038-1175) re-runs the complete
 // three-level resort to rediscover the order in which every pixel blended its Gaussians.  MI355X has 288 GB of
@@ -11,11 +11,13 @@
 //
 // Layout: one 256-thread workgroup per tile, thread -> pixel mapping identical to the forward (wave = row of four
 // 4x4 sub-tiles), log laid out [tile][wave][k][lane] so that the 64 lanes of a wave read record k with one
-// coalesced 256-byte load.  No sorting state: the kernel is a straight loop over k with the next record prefetched,
-// the entry's data read from the list-ordered entry arrays, and the nine gradient terms summed in a per-wave
-// direct-mapped LDS cache of 64-bit fixed-point sums (see stp_render_hier.inc for why not fp32 LDS atomics):
-// slot = list position mod 128, tagged; the sums of a slot go to memory (nine global atomics) only when another
-// list position claims the slot, or at the end.
+// coalesced 128-byte load.  No sorting state: the kernel is a straight loop over k with the next record prefetched,
+// the entry's data read from the list-ordered entry records, lanes on the same list position merged with DPP, and
+// the nine gradient terms summed on chip as 64-bit fixed point (see stp_render_hier.inc for why not fp32 LDS
+// atomics): tiles with at most 512 list entries keep one set of sums per POSITION for the whole workgroup, longer
+// lists go through a per-wave direct-mapped cache (slot = position mod 112, tagged) whose slots are written back
+// -- nine lanes, one atomic instruction into the Gaussian's 64-byte gradient record -- when another position claims
+// them, or at the end.  The k-buffer mode records the same log and uses this kernel as its backward too.
 #include "stp_internal.h"
 #include "stp_blend.h"
 
