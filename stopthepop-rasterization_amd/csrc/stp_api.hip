@@ -9,6 +9,7 @@
 #include "stp_internal.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -350,11 +351,14 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_TRY(launch_duplicate(f, g, radii, b, st), "duplicate launch");
     STP_DEBUG_SYNC("duplicate");
     g_timer.mark(2, st);
-    STP_TRY(launch_sort(f, b, R, st), "radix sort");
+    // STP_SORT=radix in the environment selects the reference's single full-width radix sort (+ separate entry gather)
+    static const bool tile_local_sort = !(std::getenv("STP_SORT") && std::strcmp(std::getenv("STP_SORT"), "radix") == 0);
+    STP_TRY(launch_sort(f, b, R, tile_local_sort, st), "radix sort");
     STP_DEBUG_SYNC("sort");
     STP_TRY(launch_ranges(f, b, img, R, st), "tile ranges");
     STP_DEBUG_SYNC("ranges");
-    STP_TRY(launch_gather_entries(f, g, b, R, st), "entry gather");
+    if (tile_local_sort) STP_TRY(launch_tile_sort_gather(f, g, b, img, R, st), "tile sort + entry gather");
+    else STP_TRY(launch_gather_entries(f, g, b, R, st), "entry gather");
     STP_DEBUG_SYNC("entry gather");
     g_timer.mark(3, st);
 

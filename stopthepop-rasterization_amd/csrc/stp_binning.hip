@@ -43,13 +43,15 @@ hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t
     return rocprim::inclusive_scan(g.scan_temp, bytes, g.tiles_touched, g.point_offsets, (size_t)f.P, rocprim::plus<uint32_t>(), st);
 }
 
-hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, hipStream_t st)
+// tile_bits_only: sort on the tile bits alone (two radix passes; the depth order inside every tile's segment is then
+// established by launch_tile_sort_gather, stp_tilesort.hip); otherwise the reference's full sort on bits [0, 32 + bit).
+hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, hipStream_t st)
 {
     if (R <= 0) return hipSuccess;
     const uint32_t bit = higher_msb((uint32_t)(f.gx * f.gy));
     size_t bytes = b.sort_temp_bytes;
-    return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted, b.point_list, (size_t)R, 0u,
-                                     32u + bit, st);
+    return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted, b.point_list, (size_t)R,
+                                     tile_bits_only ? 32u : 0u, 32u + bit, st);
 }
 
 } // namespace stp

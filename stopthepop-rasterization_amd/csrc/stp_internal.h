@@ -140,7 +140,8 @@ struct BackwardParams {
 hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, hipStream_t st);
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, hipStream_t st);
-hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, hipStream_t st);
+hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, hipStream_t st);
+hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st);
 hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,

@@ -1,0 +1,146 @@
+// stp_tilesort.hip -- second half of the (tile, depth) sort, fused with the entry gather.
+//
+// The reference sorts the (tile << 32 | depth) keys with one device-wide stable radix sort over 32 + log2(tiles) bits
+// (rasterizer_impl.cu:344-352): six 8-bit passes over all R pairs at C2.  A tile's list is a few hundred entries long,
+// so only the TILE bits need a device-wide pass (two radix passes: stable, so every tile's segment keeps the order
+// in which duplicate_kernel emitted it); the depth order inside a segment is then established by the tile's own
+// workgroup in LDS -- bitonic network on (depth bits, position in the segment), which is exactly the stable order
+// the full radix sort produces -- and the same workgroup writes the sorted keys, the sorted id list AND the
+// list-ordered entry records (stp_preprocess.hip: gather_entries_kernel), which it would otherwise take another pass
+// over the list to build.  Segments longer than TS_CAP entries are sorted by the workgroup with four stable 8-bit
+// counting passes through the (by then unused) unsorted arrays.  Same sorted list, bit for bit.
+#include "stp_internal.h"
+
+namespace stp {
+
+namespace {
+
+constexpr int TS_CAP = 4096; // entries a workgroup sorts in LDS (32 KB of keys + 16 KB of ids)
+
+struct TileSortArgs {
+    const uint2* ranges;
+    uint64_t* keys;           // in: grouped by tile, out: sorted
+    uint32_t* point_list;     // likewise
+    uint64_t* keys_scratch;   // the unsorted arrays: scratch of the long-segment path
+    uint32_t* list_scratch;
+    const float4* gpack;      // nullptr: no entry records (GLOBAL mode)
+    const float* features;
+    float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
+};
+
+__device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int id)
+{
+    const float4* __restrict__ gp = a.gpack + 4 * (size_t)id; // one 64-byte line written by preprocess_kernel
+    const float4 pa = gp[0], pb = gp[1], pc = gp[2], pd = gp[3];
+    a.entA[i] = pa;
+    a.entB[i] = pb;
+    a.entC[i] = make_float4(pc.x, pc.y, pc.z, __int_as_float(id));
+    a.entD[i] = pd;
+    a.entF[i] = make_float4(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2], 0.0f);
+}
+
+__global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArgs a)
+{
+    __shared__ uint64_t s_key[TS_CAP]; // (depth bits << 32) | position in the segment
+    __shared__ uint32_t s_val[TS_CAP]; // Gaussian id by position in the segment
+    const int tid = (int)threadIdx.x;
+    const uint2 range = a.ranges[blockIdx.x];
+    const int n = (int)(range.y - range.x);
+    if (n <= 0) return;
+    uint64_t* const keys = a.keys + range.x;
+    uint32_t* const list = a.point_list + range.x;
+
+    if (n <= TS_CAP) {
+        int m = 2;
+        while (m < n) m <<= 1;
+        const uint64_t tile_bits = keys[0] & 0xFFFFFFFF00000000ull;
+        for (int i = tid; i < m; i += 256) {
+            if (i < n) {
+                s_key[i] = (keys[i] << 32) | (uint32_t)i;
+                s_val[i] = list[i];
+            } else s_key[i] = ~0ull;
+        }
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int c = tid; c < (m >> 1); c += 256) {
+                    const int lo = ((c & ~(j - 1)) << 1) | (c & (j - 1));
+                    const int hi = lo | j;
+                    const bool up = (lo & k) == 0;
+                    const uint64_t x = s_key[lo], y = s_key[hi];
+                    if ((x > y) == up) { s_key[lo] = y; s_key[hi] = x; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < n; i += 256) {
+            const uint64_t k = s_key[i];
+            const int id = (int)s_val[(uint32_t)k];
+            keys[i] = tile_bits | (k >> 32);
+            list[i] = (uint32_t)id;
+            if (a.gpack) write_entry(a, (size_t)range.x + i, id);
+        }
+        return;
+    }
+
+    // ---- long segment: four stable counting passes on the depth bytes, keys/list <-> scratch ----
+    int* const s_dig = reinterpret_cast<int*>(s_val);        // [256] digit of the chunk's elements
+    int* const s_hist = reinterpret_cast<int*>(s_val) + 256; // [256]
+    int* const s_base = reinterpret_cast<int*>(s_val) + 512; // [256]
+    uint64_t* src_k = keys; uint32_t* src_v = list;
+    uint64_t* dst_k = a.keys_scratch + range.x; uint32_t* dst_v = a.list_scratch + range.x;
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[(int)((src_k[i] >> shift) & 0xFF)], 1);
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int d = 0; d < 256; d++) { s_base[d] = acc; acc += s_hist[d]; }
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 256) { // chunks in order: the pass is stable
+            const int i = c0 + tid;
+            const bool valid = i < n;
+            uint64_t k = 0; uint32_t v = 0; int d = -1;
+            if (valid) { k = src_k[i]; v = src_v[i]; d = (int)((k >> shift) & 0xFF); }
+            s_dig[tid] = d;
+            __syncthreads();
+            if (valid) {
+                int r = 0;
+                for (int u = 0; u < tid; u++) r += (int)(s_dig[u] == d);
+                dst_k[s_base[d] + r] = k;
+                dst_v[s_base[d] + r] = v;
+            }
+            __syncthreads();
+            int cnt = 0; // thread t owns digit t: advance its base by this chunk's count
+            for (int u = 0; u < 256; u++) cnt += (int)(s_dig[u] == tid);
+            s_base[tid] += cnt;
+            __syncthreads();
+        }
+        uint64_t* tk = src_k; src_k = dst_k; dst_k = tk;
+        uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
+        __threadfence_block();
+        __syncthreads();
+    }
+    // four passes: the result is back in keys / list
+    if (a.gpack)
+        for (int i = tid; i < n; i += 256) write_entry(a, (size_t)range.x + i, (int)list[i]);
+}
+
+} // namespace
+
+hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    TileSortArgs a{};
+    a.ranges = img.ranges; a.keys = b.keys; a.point_list = b.point_list; a.keys_scratch = b.keys_unsorted; a.list_scratch = b.point_list_unsorted;
+    const bool entries = f.s.sort_mode == MODE_HIER || f.s.sort_mode == MODE_KBUFFER;
+    a.gpack = entries ? g.gpack : nullptr;
+    a.features = f.colors_precomp ? f.colors_precomp : g.rgb;
+    a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
+    hipLaunchKernelGGL(tile_sort_gather_kernel, dim3(f.gx * f.gy), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace stp

@@ -281,6 +281,35 @@ def test_baseline_configs_at_reduced_area(name, scale, sd, backward):
         assert lens.max() > 512  # the long-list paths (cached replay, k-buffer retries) are what runs here
 
 
+def test_tile_lists_longer_than_the_lds_sort_capacity():
+    """A tile with more than 4096 entries: the tile-local depth sort takes its counting-pass route through the scratch
+    arrays (stp_tilesort.hip); keys, list and everything downstream must still match the oracle bit for bit."""
+    sc = scenes.make_scene(P=7000, W=24, H=20, sigma_min=6.0, sigma_max=20.0, seed=41, opacity_range=(0.02, 0.2))
+    g, f = check_against_oracle(sc, settings_dict(3, h44=True))
+    lens = np.diff(g.image_array("ranges").view(np.uint32).reshape(-1, 2), axis=1)
+    assert lens.max() > 4096, lens.ravel()
+
+
+def test_reference_style_full_radix_sort_still_selectable(monkeypatch):
+    """STP_SORT=radix (read once per process, so this runs in a child): the single full-width radix sort + separate
+    entry gather give the same frame."""
+    import subprocess, sys
+    code = ("import sys, numpy as np; sys.path[:0] = ['tests', 'stopthepop-rasterization_amd', '.']; import conftest;"
+            "from helpers import *; from diff_gaussian_rasterization import scenes;"
+            "sc = scenes.make_scene(P=3000, W=96, H=80, sigma_min=2.0, sigma_max=12.0, seed=11, camera='orbit');"
+            "g = GpuRun(sc, settings_dict(**FULL_STP)); np.save(sys.argv[1], g.color); np.save(sys.argv[2], g.binning_array('keys'))")
+    import os, tempfile
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for mode in ("radix", "tiles"):
+            env = dict(os.environ, STP_SORT=mode)
+            a, b = os.path.join(d, mode + "_c.npy"), os.path.join(d, mode + "_k.npy")
+            subprocess.run([sys.executable, "-c", code, a, b], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+            outs[mode] = (np.load(a), np.load(b))
+    assert np.array_equal(outs["radix"][1], outs["tiles"][1])
+    assert np.array_equal(outs["radix"][0], outs["tiles"][0])
+
+
 # ---------------------------------------------------------------- BASELINE-size property tests
 @pytest.fixture(scope="module")
 def c2_scene():
