@@ -15,7 +15,10 @@ namespace stp {
 
 namespace {
 
-constexpr int TS_CAP = 4096; // entries a workgroup sorts in LDS (32 KB of keys + 16 KB of ids)
+// Entries a workgroup sorts in LDS: two instantiations, launched back to back -- SMALL (12 KB of LDS: eight workgroups per
+// CU, which the latency-bound gather needs) takes the tiles with up to TS_SMALL entries and leaves at once on the others,
+// LARGE (48 KB) takes the rest, up to TS_CAP in LDS and beyond that through the counting passes.
+constexpr int TS_SMALL = 1024, TS_CAP = 4096;
 
 struct TileSortArgs {
     const uint2* ranges;
@@ -39,18 +42,19 @@ __device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int
     a.entF[i] = make_float4(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2], 0.0f);
 }
 
+template <int CAP, int MIN_N>
 __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArgs a)
 {
-    __shared__ uint64_t s_key[TS_CAP]; // (depth bits << 32) | position in the segment
-    __shared__ uint32_t s_val[TS_CAP]; // Gaussian id by position in the segment
+    __shared__ uint64_t s_key[CAP]; // (depth bits << 32) | position in the segment
+    __shared__ uint32_t s_val[CAP]; // Gaussian id by position in the segment
     const int tid = (int)threadIdx.x;
     const uint2 range = a.ranges[blockIdx.x];
     const int n = (int)(range.y - range.x);
-    if (n <= 0) return;
+    if (n <= MIN_N || (CAP == TS_SMALL && n > TS_SMALL)) return; // empty, or the other instantiation's tile
     uint64_t* const keys = a.keys + range.x;
     uint32_t* const list = a.point_list + range.x;
 
-    if (n <= TS_CAP) {
+    if (n <= CAP) {
         int m = 2;
         while (m < n) m <<= 1;
         const uint64_t tile_bits = keys[0] & 0xFFFFFFFF00000000ull;
@@ -83,6 +87,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
     }
 
     // ---- long segment: four stable counting passes on the depth bytes, keys/list <-> scratch ----
+    if constexpr (CAP == TS_SMALL) return; // (not reached: those tiles belong to the large instantiation)
     int* const s_dig = reinterpret_cast<int*>(s_val);        // [256] digit of the chunk's elements
     int* const s_hist = reinterpret_cast<int*>(s_val) + 256; // [256]
     int* const s_base = reinterpret_cast<int*>(s_val) + 512; // [256]
@@ -139,7 +144,8 @@ hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g,
     a.gpack = entries ? g.gpack : nullptr;
     a.features = f.colors_precomp ? f.colors_precomp : g.rgb;
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
-    hipLaunchKernelGGL(tile_sort_gather_kernel, dim3(f.gx * f.gy), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((tile_sort_gather_kernel<TS_SMALL, 0>), dim3(f.gx * f.gy), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((tile_sort_gather_kernel<TS_CAP, TS_SMALL>), dim3(f.gx * f.gy), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
