@@ -220,8 +220,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     _require_gpu(means3D)
     dev = means3D.device
     P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    out_color = torch.zeros((3, H, W), dtype=torch.float32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    # the render kernels write every pixel of the tile rows they cover and preprocess writes every Gaussian's radius:
+    # zero-filled outputs are only needed when nothing runs (P == 0) or when a tile-row window leaves rows untouched
+    windowed = settings_dict.get("_tile_rows") is not None
+    make = torch.zeros if (P == 0 or windowed) else torch.empty
+    out_color = make((3, H, W), dtype=torch.float32, device=dev)
+    radii = make((P,), dtype=torch.int32, device=dev)
     geom, binning, img = _Resizer(dev), _Resizer(dev, pooled=True), _Resizer(dev, pooled=True)
     rendered = 0
     if P != 0:
