@@ -186,8 +186,8 @@ def check_scratch(buf: torch.Tensor, generation: int) -> None:
     """A second backward through a retained graph after a later forward reused the buffer must not read that
     forward's blend log: fail loudly instead."""
     if generation and _big_generation.get(buf.data_ptr(), 0) != generation:
-        raise RuntimeError("the forward's blend log was recycled by a later forward pass; run the forward again "
-                           "before this backward (or set STP_BACKWARD=resort to train without a blend log)")
+        raise RuntimeError("a scratch buffer of this forward (tile lists / blend log) was recycled by a later forward "
+                           "pass; run the forward again before this backward")
 
 
 def release_scratch(buf: torch.Tensor) -> None:

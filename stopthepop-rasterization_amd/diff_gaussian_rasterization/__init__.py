@@ -73,6 +73,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.img_generation = _C.scratch_generation(imgBuffer)
+        ctx.bin_generation = _C.scratch_generation(binningBuffer)
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
         return color, radii
@@ -84,6 +85,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         (colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
         _C.check_scratch(imgBuffer, ctx.img_generation)
+        _C.check_scratch(binningBuffer, ctx.bin_generation)
         # positional layout of _C.rasterize_gaussians_backward (25 arguments)
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,

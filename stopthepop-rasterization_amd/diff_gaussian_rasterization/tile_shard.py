@@ -120,6 +120,7 @@ class _ShardedRasterize(torch.autograd.Function):
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
         ctx.rs, ctx.sdict, ctx.shard, ctx.num_rendered = rs, sdict, shard, num_rendered
         ctx.img_generation = _C.scratch_generation(imgBuffer)
+        ctx.bin_generation = _C.scratch_generation(binningBuffer)
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
         full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
@@ -134,6 +135,7 @@ class _ShardedRasterize(torch.autograd.Function):
         (colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color, geomBuffer,
          binningBuffer, imgBuffer) = ctx.saved_tensors
         _C.check_scratch(imgBuffer, ctx.img_generation)
+        _C.check_scratch(binningBuffer, ctx.bin_generation)
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, sdict, rs.debug)

@@ -310,6 +310,25 @@ def test_reference_style_full_radix_sort_still_selectable(monkeypatch):
     assert np.array_equal(outs["radix"][0], outs["tiles"][0])
 
 
+def test_second_backward_after_buffer_recycling_fails_loudly():
+    """retain_graph + a later forward that reuses the pooled scratch buffers: the second backward must raise instead
+    of replaying somebody else's tile lists."""
+    import torch
+    sc = scenes.config("C2", 0.25)  # big enough for the pooled (>= 256 MiB) buffer class
+    g = GpuRun(sc, settings_dict(**FULL_STP), backward=False)
+    t = lambda a: torch.tensor(a, device="cuda:0")
+    import diff_gaussian_rasterization as dgr
+    rast = dgr.GaussianRasterizer(g.rs)
+    m3 = t(sc.means3D).requires_grad_(True)
+    args = dict(shs=t(sc.shs), scales=t(sc.scales), rotations=t(sc.rotations))
+    color, _ = rast(m3, torch.zeros_like(m3), t(sc.opacities), **args)
+    color.sum().backward(retain_graph=True)                       # returns the buffers to the free list
+    color2, _ = rast(m3, torch.zeros_like(m3), t(sc.opacities), **args)   # ... and this forward takes them
+    with pytest.raises(RuntimeError, match="recycled"):
+        color.sum().backward()
+    color2.sum().backward()                                       # the newer graph is fine
+
+
 # ---------------------------------------------------------------- BASELINE-size property tests
 @pytest.fixture(scope="module")
 def c2_scene():
