@@ -26,8 +26,6 @@ L.stp_debug_replay_stats(out)
 (color * t(scene.dL_dout)).sum().backward()
 torch.cuda.synchronize()
 L.stp_debug_replay_stats(out)
-steps, nb, nw, dw, db = out[0], out[1], out[2], out[3], out[4]
-print(f"{workload}-{variant}: wave-steps {steps}; per step: blending lanes {nb/steps:.1f}, distinct positions among them {db/steps:.1f}, "
-      f"writer lanes after quad/row pre-reduction {nw/steps:.1f}, distinct positions among writers {dw/steps:.1f}; "
-      f"sum over quads of distinct positions {out[5]/steps:.1f}, sum over 16-lane rows {out[6]/steps:.1f}; "
-      f"cache: missing lanes {out[8]/steps:.2f}, evictions {out[7]/steps:.2f}, claim rounds {out[9]/steps:.2f}")
+steps, nw, ns = out[0], out[2], out[3]
+print(f"{workload}-{variant}: wave-steps {steps}; per step: lanes that add to LDS after the pairwise merge {nw/steps:.1f}, "
+      f"of which stragglers behind their window (global atomics) {ns/steps:.3f}")
