@@ -272,13 +272,13 @@ def test_tile_row_windows_paste_to_the_full_frame():
 ], ids=["C3_kbuffer16", "C4_fwd", "C5_full_stp", "C5_plain_hier"])
 def test_baseline_configs_at_reduced_area(name, scale, sd, backward):
     """BASELINE configs C3 / C4 / C5 with Gaussian count and image area shrunk together (same entries per tile as the
-    full-size frame: ~1100 for C3, ~1800 for C5, far beyond the replay's per-position accumulators), forward + backward
+    full-size frame: ~1100 for C3, ~1800 for C5: several windows of the replay), forward + backward
     against the oracle: image max-abs-diff and gradient max-abs-diff relative to the largest gradient."""
     sc = scenes.config(name, scale)
     g, f = check_against_oracle(sc, sd, backward=backward, exact_state=not sd["culling_settings"]["tight_opacity_bounding"])
     lens = np.diff(g.image_array("ranges").view(np.uint32).reshape(-1, 2), axis=1)
     if name != "C4":
-        assert lens.max() > 512  # the long-list paths (cached replay, k-buffer retries) are what runs here
+        assert lens.max() > 512  # the long-list path (window-by-window replay) is what runs here
 
 
 def test_tile_lists_longer_than_the_lds_sort_capacity():
