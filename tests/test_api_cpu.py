@@ -180,3 +180,15 @@ def test_two_rank_gloo_gather_and_gradient_allreduce():
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "GLOO_SHARD_OK" in outs[0]
+
+
+def test_inline_dpp_instructions_have_no_read_after_write_hazard():
+    """The hot kernels fold quad broadcasts into arithmetic with inline-asm DPP instructions; the compiler's hazard
+    recognizer does not see inside them, so the generated code is scanned: no VALU write of a DPP source register
+    in the two issue slots before its use (tools/check_dpp_hazards.py, cross-compiles for gfx950, no GPU needed)."""
+    import shutil, subprocess, sys
+    if not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("hipcc not available")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_dpp_hazards.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "DPP asm instructions" in r.stdout
