@@ -174,6 +174,11 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
    stage over the calls since stp_timing_enable(1) (6 floats, unmeasured stages are -1). */
 void stp_timing_enable(int enabled);
 int stp_timing_read(float* ms6);
+/* The text the reference hands to the SIBR viewer (DebugVisualizationData::timings_text, rasterizer_impl.cu:391-399):
+   "Timings: \n - Preprocess: <ms>ms\n - Duplicate: ...\n - Sort: ...\n - Render: ...\n - Total: <sum>ms\n" over the forward
+   stages measured since stp_timing_enable(1); measured backward stages follow as two more lines.  Writes at most
+   `size` bytes including the terminating NUL and returns the length the full text needs (as snprintf does). */
+size_t stp_timing_text(char* buf, size_t size);
 
 const char* stp_last_error(void);
 int stp_abi_version(void);

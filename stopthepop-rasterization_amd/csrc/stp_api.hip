@@ -285,6 +285,35 @@ int stp_timing_read(float* ms6)
     return 0;
 }
 
+size_t stp_timing_text(char* buf, size_t size)
+{
+    float ms[6];
+    (void)stp_timing_read(ms);
+    static const char* names[6] = {"Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess"};
+    std::string text = "Timings: \n";
+    float total = 0.0f;
+    char line[96];
+    for (int i = 0; i < 4; i++) {
+        const float v = ms[i] >= 0.0f ? ms[i] : 0.0f;
+        std::snprintf(line, sizeof(line), " - %s: %gms\n", names[i], v);
+        text += line;
+        total += v;
+    }
+    std::snprintf(line, sizeof(line), " - Total: %gms\n", total); // reference Timer::total (rasterizer_impl.h:79,131-134)
+    text += line;
+    for (int i = 4; i < 6; i++)
+        if (ms[i] >= 0.0f) {
+            std::snprintf(line, sizeof(line), " - %s: %gms\n", names[i], ms[i]);
+            text += line;
+        }
+    if (buf && size > 0) {
+        const size_t n = text.size() < size - 1 ? text.size() : size - 1;
+        std::memcpy(buf, text.data(), n);
+        buf[n] = 0;
+    }
+    return text.size();
+}
+
 int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn binning_alloc, void* binning_user,
                 stp_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
                 const StpSettings* settings, const float* means3D, const float* shs, const float* colors_precomp,

@@ -76,6 +76,8 @@ def _load():
     L.stp_timing_enable.restype = None
     L.stp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.stp_timing_read.restype = ci
+    L.stp_timing_text.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    L.stp_timing_text.restype = ctypes.c_size_t
     if L.stp_abi_version() != 4:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L
@@ -324,6 +326,13 @@ _GEOM_TYPES = {"depths": torch.float32, "clamped": torch.uint8, "radii": torch.i
 _BIN_TYPES = {"point_list": torch.int32, "point_list_unsorted": torch.int32, "keys": torch.int64, "keys_unsorted": torch.int64}
 _IMG_TYPES = {"final_T": torch.float32, "n_contrib": torch.int32, "ranges": torch.int32, "tile_flags": torch.int32,
               "blend_log": torch.int16}  # the last two exist only in a buffer of a recording forward
+
+
+def timing_text() -> str:
+    """The reference's `timings_text` (what its viewer displays), from the stages measured since timing_enable(True)."""
+    buf = ctypes.create_string_buffer(512)
+    _load().stp_timing_text(buf, 512)
+    return buf.value.decode()
 
 
 def _view(buf: torch.Tensor, off: int, count: int, dtype) -> torch.Tensor:

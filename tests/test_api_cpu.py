@@ -121,6 +121,10 @@ def test_c_abi_size_and_layout_queries_without_gpu():
     assert cnt.value == 12000 and off.value % 256 == 0
     assert L.stp_geometry_layout(1000, ctypes.byref(s), b"nonsense", ctypes.byref(off), ctypes.byref(cnt)) < 0
     assert b"nonsense" in L.stp_last_error()
+    # the viewer's timings text (reference rasterizer_impl.cu:391-399): header, four forward stages, their total
+    text = _C.timing_text()
+    assert text.startswith("Timings: \n - Preprocess: ") and " - Render: " in text and text.rstrip().endswith("ms")
+    assert [ln.split(":")[0] for ln in text.splitlines()[1:6]] == [" - Preprocess", " - Duplicate", " - Sort", " - Render", " - Total"]
 
 
 def test_settings_dict_keys_are_mandatory():

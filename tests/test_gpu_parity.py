@@ -329,6 +329,24 @@ def test_second_backward_after_buffer_recycling_fails_loudly():
     color2.sum().backward()                                       # the newer graph is fine
 
 
+def test_stage_timers_and_viewer_text():
+    """stp_timing_* (the reference's Timer, rasterizer_impl.h:77-147): means per stage over the calls since enabling,
+    and the text the viewer shows."""
+    from diff_gaussian_rasterization import _C
+    sc = scenes.make_scene(**C1)
+    _C.timing_enable(True)
+    for _ in range(3):
+        GpuRun(sc, settings_dict(**FULL_STP), backward=True)
+    ms = _C.timing_read()
+    text = _C.timing_text()
+    _C.timing_enable(False)
+    assert all(ms[k] > 0 for k in ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess")), ms
+    lines = text.splitlines()
+    assert lines[0] == "Timings: " and len(lines) == 8
+    total = float(lines[5].split(":")[1].rstrip("ms"))
+    assert abs(total - sum(ms[k] for k in ("Preprocess", "Duplicate", "Sort", "Render"))) < 1e-3 * max(total, 1.0)
+
+
 # ---------------------------------------------------------------- BASELINE-size property tests
 @pytest.fixture(scope="module")
 def c2_scene():
