@@ -235,6 +235,50 @@ template <int CAP> struct Window {
         depth[0] = fminf(depth[0], c);
         num += (int)pass;
     }
+    // ---- the always-full form used by the forward head level -------------------------------------------------------
+    // The queue always holds CAP slots: its k real entries in ascending order, preceded by CAP - k PADS of depth
+    // -FLT_MAX (store 0).  One step = the reference's "pop the front if the queue is full, then insert the candidate if
+    // it passes": the front slot is consumed by the caller -- a pad when the queue was not full, i.e. exactly when the
+    // reference does not pop -- and replace_front() puts the candidate (or a new pad, when it did not pass) into the
+    // remaining CAP - 1 slots.  No separate shift, no element count: slot s - 1 receives what the reference's swap loop
+    // leaves in slot s of the popped queue (same tie rule as insert_if), the last slot the element carried out.
+    __device__ __forceinline__ void init_padded()
+    {
+        num = 0;
+#pragma unroll
+        for (int i = 0; i < CAP; i++) { depth[i] = -FLT_MAX; store[i] = 0.0f; id[i] = 0; }
+    }
+    // `real`: c is a candidate (tie rule of the swap loop applies); otherwise c is a pad (-FLT_MAX, goes in front of
+    // every real entry WITHOUT disturbing the order of equal-depth entries -- the reference does not insert at all) or
+    // the drain filler (FLT_MAX, goes last).
+    __device__ __forceinline__ void replace_front(bool real, float c, int gid, float st)
+    {
+        if constexpr (CAP > 1) {
+            bool sw[CAP];
+            sw[1] = c < depth[1];
+#pragma unroll
+            for (int s = 2; s < CAP; s++)
+                sw[s] = (bool)((int)(c < depth[s]) & ~((int)real & (int)(c < depth[s - 1]) & (int)(depth[s - 1] == depth[s])) & 1);
+#pragma unroll
+            for (int s = 1; s < CAP; s++) {
+                const int oi = id[s];
+                const float os = store[s];
+                id[s - 1] = sw[s] ? gid : oi;
+                store[s - 1] = sw[s] ? st : os;
+                gid = sw[s] ? oi : gid;
+                st = sw[s] ? os : st;
+            }
+            float nd[CAP];
+            nd[0] = fminf(depth[1], c);
+#pragma unroll
+            for (int s = 1; s < CAP - 1; s++) nd[s] = __builtin_amdgcn_fmed3f(depth[s], depth[s + 1], c);
+            nd[CAP - 1] = fmaxf(depth[CAP - 1], c);
+#pragma unroll
+            for (int s = 0; s < CAP; s++) depth[s] = nd[s];
+        } else depth[0] = c;
+        id[CAP - 1] = gid;
+        store[CAP - 1] = st;
+    }
     // pop() where `need` holds, as selects
     __device__ __forceinline__ void pop_if(bool need)
     {
