@@ -269,10 +269,11 @@ template <int CAP> struct Window {
                 st = sw[s] ? os : st;
             }
             float nd[CAP];
-            nd[0] = fminf(depth[1], c);
+            // (min / max as medians with an infinity: one v_med3_f32 each -- fminf / fmaxf cost a canonicalising v_max first)
+            nd[0] = __builtin_amdgcn_fmed3f(-INFINITY, depth[1], c);
 #pragma unroll
             for (int s = 1; s < CAP - 1; s++) nd[s] = __builtin_amdgcn_fmed3f(depth[s], depth[s + 1], c);
-            nd[CAP - 1] = fmaxf(depth[CAP - 1], c);
+            nd[CAP - 1] = __builtin_amdgcn_fmed3f(INFINITY, depth[CAP - 1], c);
 #pragma unroll
             for (int s = 0; s < CAP; s++) depth[s] = nd[s];
         } else depth[0] = c;

@@ -65,6 +65,9 @@ __device__ __forceinline__ float quad_bcast_dyn(float v, int i)
 // instruction in the two preceding issue slots (DPP read hazard): the callers' sources come from memory loads and
 // the first use is preceded by `dpp_hazard_guard()`.
 __device__ __forceinline__ void dpp_hazard_guard() { asm volatile("s_nop 1"); }
+// The same for a value the caller has just computed with a VALU instruction: the guard takes the register in and hands
+// it out again, so the write cannot sink below it and every later read is ordered after it.
+__device__ __forceinline__ void dpp_hazard_guard_on(float& v) { asm volatile("s_nop 1" : "+v"(v)); }
 #define STP_DPP_OP3(NAME, INSTR)                                                                                              \
     template <int I> __device__ __forceinline__ float NAME(float a, float b)                                                  \
     {                                                                                                                         \
@@ -185,10 +188,12 @@ __device__ __forceinline__ float rcp_ieee(float x)
 // CUDA expf is specified to 2 ulp).
 __device__ __forceinline__ float exp_blend(float x)
 {
-    const float y = x * 1.44269502162933349609375f;
-    float r = fmaf(x, 1.44269502162933349609375f, -y);
+    // (written with -y: the error term is then a multiply-add with a literal, a VOP2 instruction; as fma(x, c, -y) it
+    // needs the VOP3 form, whose constant sits in an SGPR -- twice the issue cost on gfx950, tools/valu_rate_bench.hip)
+    const float ny = x * -1.44269502162933349609375f;
+    float r = fmaf(x, 1.44269502162933349609375f, ny);
     r = fmaf(x, 1.925963033500011e-8f, r);
-    const float g = __builtin_amdgcn_exp2f(y);
+    const float g = __builtin_amdgcn_exp2f(-ny);
     return fmaf(g, r * 0.693147182464599609375f, g);
 }
 
@@ -204,6 +209,15 @@ __device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2
     const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
     const float rcp = rcp_ieee(fmaxf(0.00001f, den));
     return num * rcp;
+}
+
+// fminf(0.99f, x) for an x that comes out of inline asm: one v_min_f32 (the compiler, not knowing that x is not a
+// signalling NaN, would canonicalise it first with a v_max_f32 x, x).  NaN -> 0.99 like fminf.
+__device__ __forceinline__ float min_099(float x)
+{
+    float r;
+    asm("v_min_f32 %0, 0x3f7d70a4, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 // depth_along_ray() for lane I's packed Sigma^-1 rows (c0 = [S00 S01 S02], c1 = [S11 S12 S22], c2 = Sigma^-1 (mu - cam)),
