@@ -84,15 +84,24 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     const double fx_scale = ldexp(1.0, 31 - md_exp), fx_inv = ldexp(1.0, md_exp - 31);
     const float fx_cap = ldexpf(1.0f, min(md_exp + 20, 126));
 
-    const log_t* const log_base = reinterpret_cast<const log_t*>(a.blend_log) + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane;
+    // Addressing: wave-uniform bases (SGPR pairs) + one 32-bit byte offset per load, so that the loop's loads are
+    // `global_load ... v_off, s[base]` without 64-bit address arithmetic (v_lshl_add_u64 issues at half the rate of a
+    // 32-bit add on gfx950, tools/valu_rate_bench.hip).
+    const char* const log_wave = reinterpret_cast<const char*>(a.blend_log) + ((size_t)(tile * 4 + __builtin_amdgcn_readfirstlane(w)) * BLEND_LOG_DEPTH) * 64 * sizeof(log_t);
+    const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
+    constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
+    auto log_at = [&](uint32_t k) __attribute__((always_inline)) -> int { // record k of this lane
+        return (int)*reinterpret_cast<const log_t*>(log_wave + (lane_off + k * LOG_ROW));
+    };
     const float pxf = (float)px, pyf = (float)py;
     const float4* const eC = a.entC + range.x; // list-ordered entry records: mean + Gaussian id, conic + opacity, colour
     const float4* const eD = a.entD + range.x;
     const float4* const eF = a.entF + range.x;
     struct Entry { float4 c, d, f; };
     auto entry_at = [&](int p) __attribute__((always_inline)) { // (a harmless read of entry 0 where there is no record: no branch)
-        const int i = p < list_len ? p : 0;
-        return Entry{eC[i], eD[i], eF[i]};
+        const uint32_t off = (uint32_t)(p < list_len ? p : 0) << 4;
+        auto at = [&](const float4* base) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off); };
+        return Entry{at(eC), at(eD), at(eF)};
     };
 
     // the gradient terms of one record (reference maths); false = nothing to add (no record, or the pixel saturates here)
@@ -188,7 +197,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         int nmax = n;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
-        int pos = (0 < n) ? (int)log_base[0] : -1, pos1 = (1 < n) ? (int)log_base[64] : -1;
+        int pos = (0 < n) ? log_at(0) : -1, pos1 = (1 < n) ? log_at(1) : -1;
         Entry en = entry_at(max(pos, 0));
         for (int k = 0; k < nmax; k++) {
             const bool have = k < n;
@@ -196,7 +205,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             // issue the next round of loads before touching this step's data
             en = entry_at(max(pos1, 0));
-            const int pos2 = (k + 2 < n) ? (int)log_base[(size_t)(k + 2) * 64] : -1;
+            const int pos2 = (k + 2 < n) ? log_at((uint32_t)k + 2) : -1;
             pos = pos1;
             pos1 = pos2;
             float g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -208,8 +217,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     } else {
     // ---- longer lists, window by window: every lane pauses at its first record beyond the window ----
     int k = 0; // records consumed by this lane
-    int pos = (0 < n) ? (int)log_base[0] : EXHAUSTED;
-    int pos1 = (1 < n) ? (int)log_base[64] : EXHAUSTED;
+    int pos = (0 < n) ? log_at(0) : EXHAUSTED;
+    int pos1 = (1 < n) ? log_at(1) : EXHAUSTED;
     Entry en = entry_at(pos);
     const int n_win = (list_len + WINDOW - 1) / WINDOW; // workgroup-uniform
     for (int win = 0; win < n_win; win++) {
@@ -221,7 +230,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             // issue the next round of loads before touching this step's data
             k += (int)act;
-            const int rec = (int)log_base[(size_t)min(k + 1, BLEND_LOG_DEPTH - 1) * 64];
+            const int rec = log_at((uint32_t)min(k + 1, BLEND_LOG_DEPTH - 1));
             pos = act ? pos1 : pos;
             pos1 = act ? (k + 1 < n ? rec : EXHAUSTED) : pos1;
             en = entry_at(pos);
