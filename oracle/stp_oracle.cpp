@@ -78,6 +78,10 @@ inline float dot3(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 inline float length3(V3 a) { return sqrtf(dot3(a, a)); }
 inline float saturate(float x) { return (x != x) ? 0.0f : (x < 0.0f ? 0.0f : (x > 1.0f ? 1.0f : x)); }
 inline float frcp(float x) { return 1.0f / x; } // round-to-nearest reciprocal
+// ln(x) rounded to fp32 from the double-precision logarithm (the reference calls logf, stopthepop_common.cuh:473,553, whose
+// CUDA implementation is within 1 ulp; the correctly rounded value is the one any two implementations can agree on -- the
+// HIP path computes it the same way, stp_device.h: log_rounded)
+inline float log_rounded(float x) { return (float)std::log((double)x); }
 
 // ------------------------------------------------------------------------------------------------
 // forward state
@@ -370,7 +374,7 @@ void preprocess(OrcFrame& f, const float* means3D, const float* shs, const float
         float co[4] = {c2z * det_inv, -c2y * det_inv, c2x * det_inv, opacity * conv_scale};
         if (co[3] < ALPHA_THRESHOLD) continue;
 
-        const float thr = logf(co[3] / ALPHA_THRESHOLD);
+        const float thr = log_rounded(co[3] / ALPHA_THRESHOLD);
         const float extent = s.tight_opacity_bounding ? (float)std::min(3.33, (double)sqrtf(2.0f * thr)) : 3.33f;
         const float mid = 0.5f * (c2x + c2z);
         const float lambda = mid + sqrtf(std::max(0.01f, mid * mid - det));
@@ -454,7 +458,7 @@ void duplicate(OrcFrame& f, const int32_t* radii, const float* inv_vp, const flo
         int x0, y0, x1, y1;
         get_rect(xy, ext, f.gx, f.gy, ty0, ty1, x0, y0, x1, y1);
         const float* co = &f.conic_opacity[4 * (size_t)idx];
-        const float thr = eval_max ? logf(co[3] / ALPHA_THRESHOLD) : 0.0f;
+        const float thr = eval_max ? log_rounded(co[3] / ALPHA_THRESHOLD) : 0.0f;
         const float global_depth = f.depths[idx];
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) {

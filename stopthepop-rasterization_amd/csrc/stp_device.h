@@ -167,6 +167,12 @@ __device__ __forceinline__ void get_rect(float2 p, float2 ext, int gx, int gy, i
     if (y1 < y0) y1 = y0;
 }
 
+// ln(x) rounded to fp32 from the double-precision logarithm: the correctly rounded value (up to double rounding, ~1e-8 of
+// the arguments), which is also what the oracle computes -- two fp32 logf implementations differ by an ulp now and then,
+// and behind this logarithm sits a ceil() that turns the ulp into a radius (tight_opacity_bounding).  Per Gaussian, not
+// per pixel: the cost does not show.
+__device__ __forceinline__ float log_rounded(float x) { return (float)log((double)x); }
+
 // 1/x, bit for bit the IEEE quotient the compiler's 12-instruction division sequence returns, in three
 // instructions: v_rcp_f32 plus one Newton step is correctly rounded for every 2^-126 <= |x| < 2^126
 // (tools/numerics_probe.hip checks all 2.1e9 positive normal floats on the device: the only mismatches are the
@@ -272,6 +278,22 @@ __device__ __forceinline__ float opacity_factor(float dx, float dy, float4 co)
 {
 #pragma clang fp contract(off)
     return 0.5f * (co.x * dx * dx + co.z * dy * dy) + co.y * dx * dy;
+}
+
+// The exponent of a blend weight, -(0.5 (a dx^2 + c dy^2) + b dx dy), in ONE canonical evaluation order without
+// contraction, used by every forward and backward kernel: the weight decides "alpha < 1/255 -> skip", and a forward and a
+// backward that round it differently disagree about which entries a pixel blended (the backward then divides the wrong
+// transmittance chain).  Same roundings as opacity_factor(), hence as the oracle's expression.
+__device__ __forceinline__ float blend_power(float dx, float dy, float4 co)
+{
+#pragma clang fp contract(off)
+    return -(0.5f * (co.x * dx * dx + co.z * dy * dy) + co.y * dx * dy);
+}
+// The same with the conic of quad lane I as DPP operands.
+template <int I> __device__ __forceinline__ float blend_power_quad(float dx, float dy, float4 co)
+{
+#pragma clang fp contract(off)
+    return -(0.5f * (quad_mul<I>(co.x, dx) * dx + quad_mul<I>(co.z, dy) * dy) + quad_mul<I>(co.y, dx) * dy);
 }
 
 // Smallest "power" (largest contribution) a Gaussian reaches inside an axis-aligned pixel rectangle

@@ -153,7 +153,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     if (co.w < ALPHA_THRESHOLD) return;
 
     // screen-space extent (reference forward.cu:151-164)
-    const float thr = logf(co.w / ALPHA_THRESHOLD);
+    const float thr = log_rounded(co.w / ALPHA_THRESHOLD);
     const float extent = a.tight_opacity_bounding ? (float)fmin(3.33, (double)sqrtf(2.0f * thr)) : 3.33f;
     const float mid = 0.5f * (c2x + c2z);
     const float lambda = mid + sqrtf(fmaxf(0.01f, mid * mid - det));
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
     float thr = 0.0f;
     if (eval_max) {
         co = a.g.conic_opacity[idx];
-        thr = logf(co.w / ALPHA_THRESHOLD);
+        thr = log_rounded(co.w / ALPHA_THRESHOLD);
     }
     float3 p0 = make_float3(0, 0, 0), p1 = p0, p2 = p0, cam = p0;
     if (per_tile_depth) {

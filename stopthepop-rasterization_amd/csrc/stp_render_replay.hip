@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             fd.xy = make_float2(cur.c.y, cur.c.z);
             fd.c[0] = cur.f.x; fd.c[1] = cur.f.y; fd.c[2] = cur.f.z;
             const float dx = fd.xy.x - pxf, dy = fd.xy.y - pyf;
-            const float power = -0.5f * (fd.co.x * dx * dx + fd.co.z * dy * dy) - fd.co.y * dx * dy;
+            const float power = blend_power(dx, dy, fd.co);
             const float G = exp_blend(power);
             ok = blend_backward_terms(bp, a, px, py, fd, G, g);
         }

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_fwd_kernel(const RenderAr
             const float2 xy = s_xy[j];
             const float4 co = s_co[j];
             const float dx = xy.x - pxf, dy = xy.y - pyf;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            const float power = blend_power(dx, dy, co);
             if (power > 0.0f) continue;
             const float alpha = fminf(0.99f, co.w * exp_blend(power));
             if (alpha < ALPHA_THRESHOLD) continue;
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
             const float2 xy = s_xy[j];
             const float4 co = s_co[j];
             const float dx = xy.x - pxf, dy = xy.y - pyf;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            const float power = blend_power(dx, dy, co);
             use = use && !(power > 0.0f);
             const float G = exp_blend(power);
             const float alpha = fminf(0.99f, co.w * G);
@@ -339,7 +339,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             const float4 eCj = s_C[j];
             const float4 co = s_D[j];
             const float dx = eCj.y - pxf, dy = eCj.z - pyf;
-            const float power = -0.5f * (co.x * dx * dx + co.z * dy * dy) - co.y * dx * dy;
+            const float power = blend_power(dx, dy, co);
             if (power > 0.0f) continue;
             const float G = exp_blend(power);
             const float alpha = fminf(0.99f, co.w * G);

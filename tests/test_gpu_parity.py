@@ -23,7 +23,7 @@ GRAD_KEYS = ("dL_dmeans2D", "dL_dopacity", "dL_dmeans3D", "dL_dscales", "dL_drot
 
 
 def _rel(a, b):
-    return max_abs(a, b) / max(float(np.max(np.abs(b))), 1e-30)
+    return max_abs(a, b) / max(float(np.max(np.abs(b))), 1e-30) if np.size(b) else 0.0
 
 
 def check_against_oracle(scene, sd, backward=True, exact_state=True):
@@ -49,8 +49,13 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True):
     # moves that one pixel by up to 1/255.  Seen: 1 pixel in 83,000 (C4 at 1 % area); allowed: 2 values in 100,000.
     diff = np.abs(g.color.astype(np.float64) - f.color.astype(np.float64))
     assert diff.max() <= 1.0 / 255.0 + 1e-6
-    assert int((diff > 2e-6).sum()) <= max(3, int(2e-5 * diff.size)), int((diff > 2e-6).sum())
+    flipped = int((diff > 2e-6).sum())
+    assert flipped <= max(3, int(2e-5 * diff.size)), flipped
     assert psnr(g.color, f.color) >= 100.0
+    # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
+    # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise
+    # (tools/fuzz_parity.py: 2 such scenes in 4000)
+    grad_tol = 1e-4 if flipped == 0 else 2e-3
     if backward:
         for k in GRAD_KEYS:
             if g.grads.get(k) is None or og.get(k) is None or og[k].size == 0:
@@ -58,7 +63,7 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True):
             a, b = g.grads[k], og[k]
             if k == "dL_dmeans2D":
                 a, b = a[:, :2], b[:, :2]
-            assert _rel(a, b) < 1e-4, k
+            assert _rel(a, b) < grad_tol, k
     return g, f
 
 

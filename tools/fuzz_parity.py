@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: random small scenes x random settings, every check of
+tests/test_gpu_parity.py::check_against_oracle (bit-exact state, image, gradients vs the CPU oracle).
+    python tools/fuzz_parity.py [--cases 150] [--seed 1] [--seconds 600]
+Prints one line per failure (with the exact reproducer) and a summary; exit code 1 on any failure."""
+import argparse, os, random, sys, time, traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "stopthepop-rasterization_amd"), ROOT):
+    sys.path.insert(0, p)
+import conftest  # noqa: F401,E402  (path setup)
+from helpers import settings_dict  # noqa: E402
+from test_gpu_parity import check_against_oracle  # noqa: E402
+from diff_gaussian_rasterization import scenes  # noqa: E402
+
+
+def random_case(rng):
+    mode = rng.choice([0, 0, 2, 2, 3, 3, 3, 3])
+    sd = dict(mode=mode, order=rng.choice([0, 1, 2, 3]), rect=rng.random() < 0.5, tight=rng.random() < 0.5,
+              tbc=rng.random() < 0.5, h44=(mode == 3 and rng.random() < 0.6), lb=rng.random() < 0.5, ewa=rng.random() < 0.3)
+    if mode == 3:
+        sd["per_pixel"], sd["tile_2x2"] = rng.choice([(4, 8), (4, 8), (8, 8), (16, 8), (4, 12), (8, 12), (16, 20), (4, 20)])
+    elif mode == 2:
+        sd["per_pixel"] = rng.choice([1, 2, 4, 8, 12, 16, 16, 20, 24])
+    smin = rng.choice([0.4, 1.0, 2.0, 4.0])
+    sc = dict(P=rng.choice([1, 7, 300, 1500, 4000, 9000]), W=rng.choice([16, 33, 64, 100, 160, 250]), H=rng.choice([16, 31, 48, 96, 130]),
+              sigma_min=smin, sigma_max=smin * rng.choice([1.5, 4.0, 10.0]), seed=rng.randrange(1, 10**6),
+              camera=rng.choice(["orbit", "orbit", "origin"]))
+    return sc, sd
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=150)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=600.0)
+    args = ap.parse_args()
+    rng = random.Random(args.seed)
+    t0, done, bad = time.time(), 0, 0
+    for i in range(args.cases):
+        if time.time() - t0 > args.seconds:
+            break
+        sc, sd = random_case(rng)
+        scene = scenes.make_scene(**sc)
+        try:
+            check_against_oracle(scene, settings_dict(**sd), backward=True, exact_state=not sd["tight"])
+        except Exception as e:  # noqa: BLE001
+            bad += 1
+            tb = traceback.extract_tb(e.__traceback__)[-1]
+            print(f"FAIL case {i}: scene={sc} settings={sd}: {type(e).__name__}: {str(e)[:200]} @ {tb.filename.split('/')[-1]}:{tb.lineno}", flush=True)
+        done += 1
+    print(f"fuzz: {done} cases, {bad} failures, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+main()
