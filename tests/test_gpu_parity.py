@@ -3,8 +3,8 @@ autograd -> _C -> C ABI of libstp_raster.so), against the CPU oracle on the same
 
 Tolerances (north_star: "within a stated fp32 tolerance, PSNR >= 60 dB"):
   * integer / index work (radii, tile counts, offsets, 64-bit sort keys, sorted lists, tile ranges): bit-exact;
-  * per-Gaussian fp32 state (means2D, conics, depths, Sigma^-1 ...): bit-exact except values downstream of
-    logf (tight_opacity_bounding extents), where host and device libm may differ by an ulp;
+  * per-Gaussian fp32 state (means2D, conics, depths, Sigma^-1 ...): bit-exact (the one logarithm on the path,
+    tight_opacity_bounding's extent, is rounded from double precision on both sides);
   * image: max-abs <= 2e-6 and PSNR >= 100 dB (the blend loops may contract a*b+c, expf differs by an ulp);
   * gradients: max-abs error <= 1e-4 of the largest entry (atomic / LDS-atomic summation order).
 """
@@ -46,11 +46,11 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True):
         assert np.array_equal(g.image_array("ranges").view(np.uint32), f.array("ranges"))
     # Image: 2e-6 everywhere, except that a blend whose alpha sits on the 1/255 (or T on the 1e-4) threshold may be
     # taken by one implementation and dropped by the other -- expf differs by an ulp between any two libraries -- which
-    # moves that one pixel by up to 1/255.  Seen: 1 pixel in 83,000 (C4 at 1 % area); allowed: 2 values in 100,000.
+    # moves that one pixel by up to 1/255.  Seen: 1 pixel in 83,000 (C4 at 1 % area); allowed: 2 values in 100,000, at least two pixels.
     diff = np.abs(g.color.astype(np.float64) - f.color.astype(np.float64))
     assert diff.max() <= 1.0 / 255.0 + 1e-6
     flipped = int((diff > 2e-6).sum())
-    assert flipped <= max(3, int(2e-5 * diff.size)), flipped
+    assert flipped <= max(6, int(2e-5 * diff.size)), flipped  # (two pixels even in a small image: seen once in 5500 random scenes)
     assert psnr(g.color, f.color) >= 100.0
     # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
     # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise
@@ -88,8 +88,7 @@ def test_c1_all_modes(sd):
 def test_dense_scene(sd):
     """~700 Gaussians per tile, off-axis rotated camera: the regime where the resorting queues actually
     reorder and hierarchical != exact sort."""
-    exact = not (sd["culling_settings"]["tight_opacity_bounding"])
-    check_against_oracle(scenes.make_scene(**DENSE), sd, exact_state=exact)
+    check_against_oracle(scenes.make_scene(**DENSE), sd)
 
 
 @pytest.mark.parametrize("head,mid", [(8, 8), (16, 8), (4, 12), (8, 12), (16, 20), (4, 20)])
@@ -216,7 +215,7 @@ def test_blend_log_mixed_tiles():
     gk, _ = check_against_oracle(sc, settings_dict(2, per_pixel=8))
     fk = gk.image_array("tile_flags")
     assert fk.any() and not fk.all(), fk
-    g, _ = check_against_oracle(sc, settings_dict(**FULL_STP), exact_state=False)
+    g, _ = check_against_oracle(sc, settings_dict(**FULL_STP))
     flags = g.image_array("tile_flags")
     assert flags.any() and not flags.all(), flags
 
@@ -225,7 +224,7 @@ def test_resorting_backward_still_selectable(monkeypatch):
     """STP_BACKWARD=resort: no log is recorded, the backward re-runs the resort (the reference's scheme)."""
     monkeypatch.setenv("STP_BACKWARD", "resort")
     sc = scenes.make_scene(**DENSE)
-    g_resort, _ = check_against_oracle(sc, settings_dict(**FULL_STP), exact_state=False)
+    g_resort, _ = check_against_oracle(sc, settings_dict(**FULL_STP))
     monkeypatch.delenv("STP_BACKWARD")
     g_replay = GpuRun(sc, settings_dict(**FULL_STP))
     assert np.array_equal(g_resort.color, g_replay.color)  # recording must not change the image
@@ -280,7 +279,7 @@ def test_baseline_configs_at_reduced_area(name, scale, sd, backward):
     full-size frame: ~1100 for C3, ~1800 for C5: several windows of the replay), forward + backward
     against the oracle: image max-abs-diff and gradient max-abs-diff relative to the largest gradient."""
     sc = scenes.config(name, scale)
-    g, f = check_against_oracle(sc, sd, backward=backward, exact_state=not sd["culling_settings"]["tight_opacity_bounding"])
+    g, f = check_against_oracle(sc, sd, backward=backward)
     lens = np.diff(g.image_array("ranges").view(np.uint32).reshape(-1, 2), axis=1)
     if name != "C4":
         assert lens.max() > 512  # the long-list path (window-by-window replay) is what runs here
