@@ -51,7 +51,7 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True):
     assert diff.max() <= 1.0 / 255.0 + 1e-6
     flipped = int((diff > 2e-6).sum())
     assert flipped <= max(6, int(2e-5 * diff.size)), flipped  # (two pixels even in a small image: seen once in 5500 random scenes)
-    assert psnr(g.color, f.color) >= 100.0
+    assert psnr(g.color, f.color) >= (100.0 if flipped == 0 else 75.0)  # (one flipped pixel of a 1600-pixel image: 80 dB)
     # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
     # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise
     # (tools/fuzz_parity.py: 2 such scenes in 4000)

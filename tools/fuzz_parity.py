@@ -25,7 +25,8 @@ def random_case(rng):
     smin = rng.choice([0.4, 1.0, 2.0, 4.0])
     sc = dict(P=rng.choice([1, 7, 300, 1500, 4000, 9000]), W=rng.choice([16, 33, 64, 100, 160, 250]), H=rng.choice([16, 31, 48, 96, 130]),
               sigma_min=smin, sigma_max=smin * rng.choice([1.5, 4.0, 10.0]), seed=rng.randrange(1, 10**6),
-              camera=rng.choice(["orbit", "orbit", "origin"]))
+              camera=rng.choice(["orbit", "orbit", "origin"]), use_sh=rng.random() < 0.8,
+              opacity_range=rng.choice([(0.05, 0.6), (0.3, 0.99), (0.004, 0.05)]), z_range=rng.choice([(2.0, 12.0), (0.5, 3.0), (0.05, 40.0)]))
     return sc, sd
 
 
@@ -42,6 +43,10 @@ def main():
             break
         sc, sd = random_case(rng)
         scene = scenes.make_scene(**sc)
+        if rng.random() < 0.3:  # lower active SH degree / different scale modifier (Scene fields the API passes through)
+            scene.sh_degree = rng.choice([0, 1, 2]) if scene.shs is not None else 0
+        if rng.random() < 0.3:
+            scene.scale_modifier = rng.choice([0.5, 0.8, 1.7])
         try:
             check_against_oracle(scene, settings_dict(**sd), backward=True)
         except Exception as e:  # noqa: BLE001
