@@ -8,6 +8,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "stp_internal.h"
+#include "stp_device.h"
 
 namespace stp {
 
@@ -52,6 +53,70 @@ hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool 
     size_t bytes = b.sort_temp_bytes;
     return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted, b.point_list, (size_t)R,
                                      tile_bits_only ? 32u : 0u, 32u + bit, st);
+}
+
+// ---- binning by tile counters (STP_SORT=counters; not the default, see stp_api.hip) ----------------------------------
+// The reference (and the default path) brings the duplicates into tile order with a device-wide radix sort of all R
+// (key, id) pairs.  The tile of every duplicate is known when it is emitted, and a tile's segment length is known once
+// every Gaussian has been preprocessed: preprocess_kernel counts entries per tile (one fire-and-forget atomic per
+// duplicate), tile_scan_kernel turns the counters into the tile ranges (an exclusive prefix sum over T <= a few 10^4
+// tiles: one workgroup) and duplicate_kernel writes each duplicate straight into its tile's segment through an atomic
+// cursor.  The order INSIDE a segment is whatever the atomics gave; the tile's own workgroup then sorts it by
+// (depth, Gaussian id), which is the order a stable sort of duplicates emitted in Gaussian order produces
+// (stp_tilesort.hip) -- same sorted list, bit for bit, no device-wide sort pass, no identifyTileRanges pass.
+namespace {
+
+constexpr int SCAN_THREADS = 1024;
+
+__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int T, const uint32_t* __restrict__ counts, uint2* __restrict__ ranges,
+                                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ total)
+{
+    __shared__ uint32_t s_part[SCAN_THREADS];
+    const int tid = (int)threadIdx.x;
+    const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
+    const int lo = min(tid * per, T), hi = min(lo + per, T);
+    uint32_t sum = 0;
+    for (int t = lo; t < hi; t++) sum += counts[t];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < SCAN_THREADS; off <<= 1) { // inclusive scan of the per-thread sums
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[tid] - sum;
+    for (int t = lo; t < hi; t++) {
+        const uint32_t c = counts[t];
+        ranges[t] = c ? make_uint2(run, run + c) : make_uint2(0u, 0u); // (an empty tile keeps the (0, 0) of the reference's memset)
+        cursor[t] = run;
+        run += c;
+    }
+    if (tid == SCAN_THREADS - 1) total[0] = s_part[tid];
+}
+
+// entries [total, R): duplicates that preprocess counted and culling then dropped (reference stopthepop_common.cuh:503-508)
+__global__ void __launch_bounds__(256) bin_pad_kernel(int R, const uint32_t* __restrict__ total, uint64_t* __restrict__ keys, uint32_t* __restrict__ list)
+{
+    for (int i = (int)total[0] + (int)threadIdx.x; i < R; i += 256) {
+        keys[i] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
+        list[i] = 0xFFFFFFFFu;
+    }
+}
+
+} // namespace
+
+hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st)
+{
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, f.gx * f.gy, img.tile_counts, img.ranges, img.tile_cursor, img.bin_total);
+    return hipGetLastError();
+}
+
+hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st)
+{
+    if (R <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bin_pad_kernel, dim3(1), dim3(256), 0, st, R, img.bin_total, b.keys, b.point_list);
+    return hipGetLastError();
 }
 
 } // namespace stp

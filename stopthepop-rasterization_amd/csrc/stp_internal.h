@@ -70,6 +70,11 @@ struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges 
     uint32_t* n_contrib; // N
     uint2* ranges;       // T
     uint32_t* dbg_minmax; // 2 (debug depth visualisation: the frame's extrema, as order-preserving integers)
+    // Binning by tile counters (stp_binning.hip: "atomic binning"): entries per tile counted by preprocess_kernel, the
+    // next free slot of every tile's segment while duplicate_kernel fills it, and [0] = entries over all tiles.
+    uint32_t* tile_counts; // T
+    uint32_t* tile_cursor; // T
+    uint32_t* bin_total;   // 2
     uint32_t* tile_flags; // T   (only with the blend log)
     uint32_t* blend_log;  // T * 4 waves * BLEND_LOG_DEPTH * 64 lanes (only with the blend log)
 };
@@ -137,11 +142,13 @@ struct BackwardParams {
 };
 
 // ---- launchers (one per stage; each returns hipSuccess or the launch error) ----
-hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, hipStream_t st);
+hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, uint32_t* tile_counts, hipStream_t st); // tile_counts: nullptr = do not count per tile
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, hipStream_t st);
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays
+hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
+hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, hipStream_t st);
-hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, hipStream_t st);
+hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, bool unordered, hipStream_t st);
 hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st);
 hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img,

@@ -35,6 +35,7 @@ struct PreArgs {
     const float* cam;
     int* radii;
     GeometryState g;
+    uint32_t* tile_counts; // binning by tile counters: entries per tile (nullptr: not counted)
 };
 
 // SH -> RGB, reference forward_common.h:20-70 (same association of the sums)
@@ -191,9 +192,14 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
                 const float f = max_contrib_power_rect(co, mean2D, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), mp);
                 const int hit = (f <= thr) ? 1 : 0;
                 full_count += hit;
-                tile_count += (y >= y0 && y < y1) ? hit : 0;
+                const int mine = (y >= y0 && y < y1) ? hit : 0;
+                tile_count += mine;
+                if (mine && a.tile_counts) atomicAdd(&a.tile_counts[y * a.gx + x], 1u);
             }
         if (full_count == 0) return;
+    } else if (a.tile_counts) {
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) atomicAdd(&a.tile_counts[y * a.gx + x], 1u);
     }
 
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
@@ -246,6 +252,7 @@ struct DupArgs {
     GeometryState g;
     uint64_t* keys;
     uint32_t* values;
+    uint32_t* tile_cursor; // binning by tile counters: next free slot of every tile's segment (nullptr: slots by point_offsets)
 };
 
 __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
@@ -295,13 +302,20 @@ __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
             }
             const bool write = !tbc || max_fac <= thr;
             if (write) {
-                if (off < off_to) {
+                const uint32_t tile = (uint32_t)(y * a.gx + x);
+                if (a.tile_cursor) { // straight into the tile's segment; the order inside it is settled by the tile sort
+                    const uint32_t slot = atomicAdd(&a.tile_cursor[tile], 1u);
+                    a.values[slot] = (uint32_t)idx;
+                    a.keys[slot] = make_sort_key(tile, depth);
+                } else if (off < off_to) {
                     a.values[off] = (uint32_t)idx;
-                    a.keys[off] = make_sort_key((uint32_t)(y * a.gx + x), depth);
+                    a.keys[off] = make_sort_key(tile, depth);
                 }
                 off++;
             }
         }
+    if (a.tile_cursor) return; // (entries that preprocess counted but culling dropped -- none, the two tests are the same
+                               //  function -- would be padded by bin_pad_kernel behind the last segment)
     // pad what the (slightly more generous) preprocess count reserved but culling did not use
     // (reference stopthepop_common.cuh:503-508, 614-619)
     for (; off < off_to; off++) {
@@ -339,7 +353,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* _
 
 } // namespace
 
-hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, hipStream_t st)
+hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, uint32_t* tile_counts, hipStream_t st)
 {
     PreArgs a;
     a.P = f.P; a.D = f.D; a.M = f.M; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
@@ -348,17 +362,19 @@ hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* 
     a.tile_based_culling = f.s.tile_based_culling; a.proper_ewa_scaling = f.s.proper_ewa_scaling; a.prefiltered = f.prefiltered;
     a.means3D = f.means3D; a.scales = f.scales; a.rotations = f.rotations; a.opacities = f.opacities; a.shs = f.shs;
     a.cov3D_precomp = f.cov3D_precomp; a.colors_precomp = f.colors_precomp; a.view = f.viewmatrix; a.proj = f.projmatrix; a.cam = f.cam_pos;
-    a.radii = radii; a.g = g;
+    a.radii = radii; a.g = g; a.tile_counts = tile_counts;
     hipLaunchKernelGGL(preprocess_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, hipStream_t st)
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, hipStream_t st)
 {
     DupArgs a;
     a.P = f.P; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
     a.sort_order = f.s.sort_order; a.tile_based_culling = f.s.tile_based_culling;
-    a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.radii = radii; a.g = g; a.keys = b.keys_unsorted; a.values = b.point_list_unsorted;
+    a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.radii = radii; a.g = g;
+    a.tile_cursor = tile_cursor;
+    a.keys = tile_cursor ? b.keys : b.keys_unsorted; a.values = tile_cursor ? b.point_list : b.point_list_unsorted;
     hipLaunchKernelGGL(duplicate_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -1,23 +1,25 @@
 // stp_tilesort.hip -- second half of the (tile, depth) sort, fused with the entry gather.
 //
 // The reference sorts the (tile << 32 | depth) keys with one device-wide stable radix sort over 32 + log2(tiles) bits
-// (rasterizer_impl.cu:344-352): six 8-bit passes over all R pairs at C2.  A tile's list is a few hundred entries long,
-// so only the TILE bits need a device-wide pass (two radix passes: stable, so every tile's segment keeps the order
-// in which duplicate_kernel emitted it); the depth order inside a segment is then established by the tile's own
-// workgroup in LDS -- bitonic network on (depth bits, position in the segment), which is exactly the stable order
-// the full radix sort produces -- and the same workgroup writes the sorted keys, the sorted id list AND the
-// list-ordered entry records (stp_preprocess.hip: gather_entries_kernel), which it would otherwise take another pass
-// over the list to build.  Segments longer than TS_CAP entries are sorted by the workgroup with four stable 8-bit
-// counting passes through the (by then unused) unsorted arrays.  Same sorted list, bit for bit.
+// (rasterizer_impl.cu:344-352): six 8-bit passes over all R pairs at C2.  A tile's list is a few hundred entries long:
+// once the duplicates are grouped by tile (a radix sort on the tile bits only -- two passes; or, STP_SORT=counters, through
+// per-tile counters without any sort pass, stp_binning.hip), the depth order inside a segment is established by the tile's own workgroup in
+// LDS -- bitonic network on (depth bits, Gaussian id).  The reference's stable sort leaves equal (tile, depth) keys in
+// the order duplicateWithKeys emitted them, which is the order of the Gaussian index: the id as the minor key gives
+// exactly that list whatever order the segment arrived in.  The same workgroup writes the sorted keys, the sorted id
+// list AND the list-ordered entry records (stp_preprocess.hip: gather_entries_kernel), which it would otherwise take
+// another pass over the list to build.  Segments longer than TS_CAP entries are sorted by the workgroup with stable
+// 8-bit counting passes (id bytes first when the segment is not in id order yet, then the four depth bytes) through the
+// otherwise unused unsorted arrays.  Same sorted list, bit for bit.
 #include "stp_internal.h"
 
 namespace stp {
 
 namespace {
 
-// Entries a workgroup sorts in LDS: two instantiations, launched back to back -- SMALL (12 KB of LDS: eight workgroups per
-// CU, which the latency-bound gather needs) takes the tiles with up to TS_SMALL entries and leaves at once on the others,
-// LARGE (48 KB) takes the rest, up to TS_CAP in LDS and beyond that through the counting passes.
+// Entries a workgroup sorts in LDS: two instantiations, launched back to back -- SMALL (8 KB of LDS: the latency-bound
+// gather wants many workgroups per CU) takes the tiles with up to TS_SMALL entries and leaves at once on the others,
+// LARGE (32 KB) takes the rest, up to TS_CAP in LDS and beyond that through the counting passes.
 constexpr int TS_SMALL = 1024, TS_CAP = 4096;
 
 struct TileSortArgs {
@@ -28,6 +30,7 @@ struct TileSortArgs {
     uint32_t* list_scratch;
     const float4* gpack;      // nullptr: no entry records (GLOBAL mode)
     const float* features;
+    int id_passes;            // long segments: counting passes on the id bytes before the depth passes (0: already in id order)
     float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
 };
 
@@ -45,8 +48,8 @@ __device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int
 template <int CAP, int MIN_N>
 __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArgs a)
 {
-    __shared__ uint64_t s_key[CAP]; // (depth bits << 32) | position in the segment
-    __shared__ uint32_t s_val[CAP]; // Gaussian id by position in the segment
+    __shared__ uint64_t s_key[CAP]; // (depth bits << 32) | Gaussian id
+    __shared__ int s_cnt[3 * 256];  // long segments only: digits of a chunk, histogram, bases
     const int tid = (int)threadIdx.x;
     const uint2 range = a.ranges[blockIdx.x];
     const int n = (int)(range.y - range.x);
@@ -59,10 +62,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
         while (m < n) m <<= 1;
         const uint64_t tile_bits = keys[0] & 0xFFFFFFFF00000000ull;
         for (int i = tid; i < m; i += 256) {
-            if (i < n) {
-                s_key[i] = (keys[i] << 32) | (uint32_t)i;
-                s_val[i] = list[i];
-            } else s_key[i] = ~0ull;
+            s_key[i] = i < n ? ((keys[i] << 32) | list[i]) : ~0ull;
         }
         __syncthreads();
         for (int k = 2; k <= m; k <<= 1)
@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
             }
         for (int i = tid; i < n; i += 256) {
             const uint64_t k = s_key[i];
-            const int id = (int)s_val[(uint32_t)k];
+            const int id = (int)(uint32_t)k;
             keys[i] = tile_bits | (k >> 32);
             list[i] = (uint32_t)id;
             if (a.gpack) write_entry(a, (size_t)range.x + i, id);
@@ -86,18 +86,21 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
         return;
     }
 
-    // ---- long segment: four stable counting passes on the depth bytes, keys/list <-> scratch ----
+    // ---- long segment: stable counting passes (LSD: id bytes if needed, then the four depth bytes), keys/list <-> scratch ----
     if constexpr (CAP == TS_SMALL) return; // (not reached: those tiles belong to the large instantiation)
-    int* const s_dig = reinterpret_cast<int*>(s_val);        // [256] digit of the chunk's elements
-    int* const s_hist = reinterpret_cast<int*>(s_val) + 256; // [256]
-    int* const s_base = reinterpret_cast<int*>(s_val) + 512; // [256]
+    int* const s_dig = s_cnt;         // [256] digit of the chunk's elements
+    int* const s_hist = s_cnt + 256;  // [256]
+    int* const s_base = s_cnt + 512;  // [256]
     uint64_t* src_k = keys; uint32_t* src_v = list;
     uint64_t* dst_k = a.keys_scratch + range.x; uint32_t* dst_v = a.list_scratch + range.x;
-    for (int pass = 0; pass < 4; pass++) {
-        const int shift = 8 * pass;
+    const int n_pass = a.id_passes + 4;
+    for (int pass = 0; pass < n_pass; pass++) {
+        const bool on_id = pass < a.id_passes;
+        const int shift = 8 * (on_id ? pass : pass - a.id_passes);
+        auto digit = [&](uint64_t k, uint32_t v) __attribute__((always_inline)) { return (int)(((on_id ? (uint64_t)v : k) >> shift) & 0xFF); };
         s_hist[tid] = 0;
         __syncthreads();
-        for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[(int)((src_k[i] >> shift) & 0xFF)], 1);
+        for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[digit(src_k[i], src_v[i])], 1);
         __syncthreads();
         if (tid == 0) {
             int acc = 0;
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
             const int i = c0 + tid;
             const bool valid = i < n;
             uint64_t k = 0; uint32_t v = 0; int d = -1;
-            if (valid) { k = src_k[i]; v = src_v[i]; d = (int)((k >> shift) & 0xFF); }
+            if (valid) { k = src_k[i]; v = src_v[i]; d = digit(k, v); }
             s_dig[tid] = d;
             __syncthreads();
             if (valid) {
@@ -128,17 +131,24 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
         __threadfence_block();
         __syncthreads();
     }
-    // four passes: the result is back in keys / list
+    if (n_pass & 1) { // an odd number of passes leaves the result in the scratch arrays
+        for (int i = tid; i < n; i += 256) { keys[i] = src_k[i]; list[i] = src_v[i]; }
+        __threadfence_block();
+        __syncthreads();
+    }
     if (a.gpack)
         for (int i = tid; i < n; i += 256) write_entry(a, (size_t)range.x + i, (int)list[i]);
 }
 
 } // namespace
 
-hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, hipStream_t st)
+hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, bool unordered, hipStream_t st)
 {
     if (R <= 0) return hipSuccess;
     TileSortArgs a{};
+    a.id_passes = 0;
+    if (unordered) // segments filled through atomic cursors: not in id order
+        for (unsigned int top = (unsigned int)(f.P > 1 ? f.P - 1 : 1); top; top >>= 8) a.id_passes++;
     a.ranges = img.ranges; a.keys = b.keys; a.point_list = b.point_list; a.keys_scratch = b.keys_unsorted; a.list_scratch = b.point_list_unsorted;
     const bool entries = f.s.sort_mode == MODE_HIER || f.s.sort_mode == MODE_KBUFFER;
     a.gpack = entries ? g.gpack : nullptr;

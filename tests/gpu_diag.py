@@ -43,7 +43,6 @@ def one(tag, scene, sd, backward=True):
         if nm == "rgb" and scene.shs is None: continue
         cmp_stage(tag, nm, ga, oa)
     if f.num_rendered == g.num_rendered and f.num_rendered > 0:
-        cmp_stage(tag, "keys_unsorted", g.binning_array("keys_unsorted"), f.array("keys_unsorted"))
         cmp_stage(tag, "keys", g.binning_array("keys"), f.array("keys"))
         cmp_stage(tag, "point_list", g.binning_array("point_list"), f.array("point_list"))
         cmp_stage(tag, "ranges", g.image_array("ranges").view(np.uint32), f.array("ranges"))

@@ -294,24 +294,30 @@ def test_tile_lists_longer_than_the_lds_sort_capacity():
     assert lens.max() > 4096, lens.ravel()
 
 
-def test_reference_style_full_radix_sort_still_selectable(monkeypatch):
-    """STP_SORT=radix (read once per process, so this runs in a child): the single full-width radix sort + separate
-    entry gather give the same frame."""
+@pytest.mark.parametrize("scene_kw", [
+    "P=3000, W=96, H=80, sigma_min=2.0, sigma_max=12.0, seed=11, camera='orbit'",
+    "P=7000, W=24, H=20, sigma_min=6.0, sigma_max=20.0, seed=41, opacity_range=(0.02, 0.2)"], ids=["dense", "lists_over_4096"])
+def test_reference_style_full_radix_sort_still_selectable(monkeypatch, scene_kw):
+    """STP_SORT (read once per process, so this runs in children): the reference's single full-width radix sort +
+    separate entry gather ("radix"), the default (radix sort on the tile bits + per-tile sort) and binning by tile
+    counters + per-tile sort ("counters") give the same sorted list and the same frame."""
     import subprocess, sys
     code = ("import sys, numpy as np; sys.path[:0] = ['tests', 'stopthepop-rasterization_amd', '.']; import conftest;"
             "from helpers import *; from diff_gaussian_rasterization import scenes;"
-            "sc = scenes.make_scene(P=3000, W=96, H=80, sigma_min=2.0, sigma_max=12.0, seed=11, camera='orbit');"
-            "g = GpuRun(sc, settings_dict(**FULL_STP)); np.save(sys.argv[1], g.color); np.save(sys.argv[2], g.binning_array('keys'))")
+            f"sc = scenes.make_scene({scene_kw});"
+            "g = GpuRun(sc, settings_dict(3, h44=True)); np.save(sys.argv[1], g.color); np.save(sys.argv[2], g.binning_array('keys'));"
+            "np.save(sys.argv[2] + '.list.npy', g.binning_array('point_list'))")
     import os, tempfile
     with tempfile.TemporaryDirectory() as d:
         outs = {}
-        for mode in ("radix", "tiles"):
+        for mode in ("radix", "default", "counters"):
             env = dict(os.environ, STP_SORT=mode)
             a, b = os.path.join(d, mode + "_c.npy"), os.path.join(d, mode + "_k.npy")
             subprocess.run([sys.executable, "-c", code, a, b], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-            outs[mode] = (np.load(a), np.load(b))
-    assert np.array_equal(outs["radix"][1], outs["tiles"][1])
-    assert np.array_equal(outs["radix"][0], outs["tiles"][0])
+            outs[mode] = (np.load(a), np.load(b), np.load(b + ".list.npy"))
+    for mode in ("default", "counters"):
+        for part in (1, 2, 0):  # sorted keys, sorted id list, frame
+            assert np.array_equal(outs["radix"][part], outs[mode][part]), (mode, part)
 
 
 def test_second_backward_after_buffer_recycling_fails_loudly():
@@ -370,7 +376,9 @@ def test_c2_full_size_properties(c2_scene):
     bit = int(np.ceil(np.log2(T + 1)))
     masked = keys & np.uint64((1 << (32 + bit)) - 1)
     assert np.all(masked[1:] >= masked[:-1])                            # sortedness on the sorted bit range
-    assert np.array_equal(np.sort(g.binning_array("keys_unsorted")), np.sort(keys))   # the sort is a permutation
+    ids = g.binning_array("point_list")
+    vis_ids = np.nonzero(tiles)[0]
+    assert np.array_equal(np.bincount(ids[ids != 0xFFFFFFFF].astype(np.int64), minlength=c2_scene.P)[vis_ids], tiles[vis_ids])  # every Gaussian appears tiles_touched times
     ranges = g.image_array("ranges").view(np.uint32).reshape(-1, 2)
     valid_tiles = (keys >> np.uint64(32)) < T
     assert int((ranges[:, 1] - ranges[:, 0]).astype(np.int64).sum()) == int(valid_tiles.sum())  # ranges tile the valid part
