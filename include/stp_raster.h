@@ -171,7 +171,8 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
    "Preprocess","Duplicate","Sort","Render", rasterizer_impl.cu:248) plus "BwdRender","BwdPreprocess".
    While enabled, every forward/backward records hipEvents around its stages on the call's stream (no extra
    host synchronisation); stp_timing_read waits for the recorded events and returns the MEAN milliseconds per
-   stage over the calls since stp_timing_enable(1) (6 floats, unmeasured stages are -1). */
+   stage over the calls since stp_timing_enable(1) (6 floats, unmeasured stages are -1).  One process-wide timer: enable
+   it from one thread only (the rest of the API is re-entrant). */
 void stp_timing_enable(int enabled);
 int stp_timing_read(float* ms6);
 /* The text the reference hands to the SIBR viewer (DebugVisualizationData::timings_text, rasterizer_impl.cu:391-399):

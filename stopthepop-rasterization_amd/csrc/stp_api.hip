@@ -4,8 +4,12 @@
 // rasterizer_impl.cu:175-217.
 //
 // Stage order of a forward is the reference's: preprocess -> inclusive scan -> (one host read-back of
-// num_rendered) -> duplicate -> radix sort on bits [0,32+bit) -> tile ranges -> render.  Everything is
-// enqueued on the caller's stream; the only host synchronisation is the read-back.
+// num_rendered) -> duplicate -> sort -> tile ranges -> render, where "sort" is by default a radix sort on the tile bits
+// followed by the per-tile (depth, id) sort fused with the entry gather (stp_tilesort.hip; STP_SORT selects the
+// alternatives, see stp_forward).  Everything is enqueued on the caller's stream; the only host synchronisation is
+// the read-back.  The calls are re-entrant (no shared mutable state: the scratch buffers belong to the caller,
+// stp_last_error is per thread) EXCEPT for the optional stage timer, which is one process-wide instance meant for a
+// single timed caller (bench.py, the viewer's timings text).
 #include "stp_internal.h"
 
 #include <cstdio>
