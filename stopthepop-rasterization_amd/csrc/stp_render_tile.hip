@@ -247,6 +247,22 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
 // ------------------------------------------------------------------------------------------------
 // PPX_KBUFFER forward / backward: per-pixel sorted window keyed by depth along the pixel's own ray
 // ------------------------------------------------------------------------------------------------
+// Minimum over the rectangle [x0,x1] x [y0,y1] of offsets (pixel - mean) of q(dx,dy) = 0.5 (a dx^2 + c dy^2) + b dx dy,
+// the negated blend exponent (co = (a, b, c, opacity)).  q is convex for a positive definite conic: the minimum is 0 when
+// the mean lies inside, otherwise it is on the boundary -- on each of the four edges a one-dimensional parabola whose
+// vertex is clamped to the edge.  Anything unexpected (a or c not positive, NaN) returns 0, i.e. "may contribute".
+__device__ __forceinline__ float min_power_rect(float4 co, float x0, float x1, float y0, float y1)
+{
+    const float A = co.x, B = co.y, C = co.z;
+    if (!(A > 0.0f && C > 0.0f)) return 0.0f;
+    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return 0.0f;
+    auto q = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
+    auto on_x_edge = [&](float X) { return q(X, fminf(fmaxf(-B * X / C, y0), y1)); }; // dx = X fixed, dy free in [y0, y1]
+    auto on_y_edge = [&](float Y) { return q(fminf(fmaxf(-B * Y / A, x0), x1), Y); };
+    const float m = fminf(fminf(on_x_edge(x0), on_x_edge(x1)), fminf(on_y_edge(y0), on_y_edge(y1)));
+    return m == m ? fmaxf(m, 0.0f) : 0.0f;
+}
+
 // MODE 0 = forward, 1 = backward that re-runs the window sort (the reference's scheme; nine atomics per blended pair),
 // 2 = training forward: additionally records every pixel's blend order in the blend log, so that the backward is the
 // replay kernel of stp_render_replay.hip (the same log format and thread -> pixel mapping as the hierarchical mode).
@@ -264,6 +280,14 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     __shared__ float4 s_B[BLOCK];
     __shared__ float4 s_C[BLOCK];
     __shared__ float4 s_D[BLOCK];
+    // Strip pre-test (ours; results unchanged): a wave's pixels are four rows of the tile, and most entries of a tile's
+    // list cannot reach alpha >= 1/255 anywhere in a given 16x4 strip.  The thread that stages an entry computes the
+    // EXACT minimum of the exponent's quadratic form over each of the four strips (min_power_rect below -- not the
+    // reference's max-contribution estimate, stopthepop_common.cuh:130-174, which in the corner case returns an interior
+    // point and is therefore not a bound) and leaves four bits; a wave skips the per-pixel evaluation of an entry whose
+    // bit is clear (with a margin of 1e-3 on the threshold against rounding: a skipped entry fails the exact per-pixel
+    // test for every pixel of the strip).  The pop-before-look step and the contributor count still run.
+    __shared__ uint32_t s_hit[BLOCK];
 
     TileCtx c = tile_ctx(a);
     if constexpr (BACKWARD) {
@@ -327,8 +351,17 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             const size_t gi = (size_t)c.range.x + progress;
             s_A[threadIdx.x] = a.entA[gi];
             s_B[threadIdx.x] = a.entB[gi];
-            s_C[threadIdx.x] = a.entC[gi];
-            s_D[threadIdx.x] = a.entD[gi];
+            const float4 sc = a.entC[gi], sd = a.entD[gi];
+            s_C[threadIdx.x] = sc;
+            s_D[threadIdx.x] = sd;
+            uint32_t hit = 0;
+#pragma unroll
+            for (int ww = 0; ww < 4; ww++) {
+                const float x0 = (float)(c.tx * TILE), y0 = (float)(c.ty * TILE + 4 * ww);
+                const float p = min_power_rect(sd, x0 - sc.y, x0 + 15.0f - sc.y, y0 - sc.z, y0 + 3.0f - sc.z);
+                hit |= (sd.w * exp_blend(-p) < ALPHA_THRESHOLD * 0.999f) ? 0u : (1u << ww);
+            }
+            s_hit[threadIdx.x] = hit;
         }
         __syncthreads();
         const int n = min(BLOCK, todo);
@@ -336,6 +369,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             if (win.num == WIN) blend_one(); // before the next candidate is looked at
             if (done) break;
             contributor++;
+            if (((s_hit[j] >> w) & 1u) == 0u) continue; // (the same for every lane of the wave)
             const float4 eCj = s_C[j];
             const float4 co = s_D[j];
             const float dx = eCj.y - pxf, dy = eCj.z - pyf;
