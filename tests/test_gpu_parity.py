@@ -26,7 +26,10 @@ def _rel(a, b):
     return max_abs(a, b) / max(float(np.max(np.abs(b))), 1e-30) if np.size(b) else 0.0
 
 
-def check_against_oracle(scene, sd, backward=True, exact_state=True):
+def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-6, grad_tol=1e-4, flip_grad_tol=2e-3, max_flipped=6):
+    """img_tol / grad_tol: the fixed test scenes blend tens of entries per pixel; tools/fuzz_parity.py --heavy (hundreds to
+    a thousand blends per pixel, opacities at the 1/255 threshold) passes looser ones -- fp32 rounding accumulates with
+    the number of blends, and a faint Gaussian's whole gradient can hang on one threshold decision."""
     g = GpuRun(scene, sd, backward=backward)
     f, og = oracle_run(scene, sd, backward=backward)
     assert g.num_rendered == f.num_rendered
@@ -49,13 +52,13 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True):
     # moves that one pixel by up to 1/255.  Seen: 1 pixel in 83,000 (C4 at 1 % area); allowed: 2 values in 100,000, at least two pixels.
     diff = np.abs(g.color.astype(np.float64) - f.color.astype(np.float64))
     assert diff.max() <= 1.0 / 255.0 + 1e-6
-    flipped = int((diff > 2e-6).sum())
-    assert flipped <= max(6, int(2e-5 * diff.size)), flipped  # (two pixels even in a small image: seen once in 5500 random scenes)
+    flipped = int((diff > img_tol).sum())
+    assert flipped <= max(max_flipped, int(2e-5 * diff.size)), flipped  # (two pixels even in a small image: seen once in 5500 random scenes)
     assert psnr(g.color, f.color) >= (100.0 if flipped == 0 else 75.0)  # (one flipped pixel of a 1600-pixel image: 80 dB)
     # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
     # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise
     # (tools/fuzz_parity.py: 2 such scenes in 4000)
-    grad_tol = 1e-4 if flipped == 0 else 2e-3
+    grad_tol = grad_tol if flipped == 0 else flip_grad_tol
     if backward:
         for k in GRAD_KEYS:
             if g.grads.get(k) is None or og.get(k) is None or og[k].size == 0:
@@ -283,6 +286,22 @@ def test_baseline_configs_at_reduced_area(name, scale, sd, backward):
     lens = np.diff(g.image_array("ranges").view(np.uint32).reshape(-1, 2), axis=1)
     if name != "C4":
         assert lens.max() > 512  # the long-list path (window-by-window replay) is what runs here
+
+
+@pytest.mark.parametrize("sd", [settings_dict(3), settings_dict(3, h44=True), settings_dict(**FULL_STP), settings_dict(3, per_pixel=8, tile_2x2=12),
+                                settings_dict(2, per_pixel=16), settings_dict(0)], ids=["hier", "hier_cull", "full_stp", "hier_8_12", "kbuffer16", "global"])
+def test_exact_depth_ties(sd):
+    """Every Gaussian exists twice (same geometry, different colour and opacity): bit-identical depths along every ray, at
+    every level.  The global sort keeps list order (stable), the tail's Batcher network does NOT (the reference's network
+    is unstable: the HIP path redoes such a batch with the network itself), the mid level ranks by lane, the head's swap
+    loop has its own rule -- all of it must come out as in the oracle."""
+    import dataclasses
+    base = scenes.make_scene(P=2500, W=80, H=64, sigma_min=2.0, sigma_max=12.0, seed=77, camera="orbit")
+    tw = lambda a: None if a is None else np.concatenate([a, a], axis=0)
+    sc = dataclasses.replace(base, means3D=tw(base.means3D), scales=tw(base.scales), rotations=tw(base.rotations),
+                             opacities=np.concatenate([base.opacities, (0.7 * base.opacities).astype(np.float32)], axis=0),
+                             shs=np.concatenate([base.shs, base.shs[::-1]], axis=0), colors_precomp=None)
+    check_against_oracle(sc, sd)
 
 
 def test_tile_lists_longer_than_the_lds_sort_capacity():

@@ -14,6 +14,23 @@ from test_gpu_parity import check_against_oracle  # noqa: E402
 from diff_gaussian_rasterization import scenes  # noqa: E402
 
 
+def heavy_case(rng):
+    """Dense scenes: hundreds to thousands of entries per tile, many blends per pixel (blend-log overflow, lists beyond the LDS
+    sort capacity, several replay windows)."""
+    mode = rng.choice([2, 3, 3, 3])
+    sd = dict(mode=mode, order=rng.choice([0, 1, 2, 3]), rect=rng.random() < 0.5, tight=rng.random() < 0.5,
+              tbc=rng.random() < 0.5, h44=(mode == 3 and rng.random() < 0.6), lb=True, ewa=rng.random() < 0.2)
+    if mode == 3:
+        sd["per_pixel"], sd["tile_2x2"] = rng.choice([(4, 8), (4, 8), (8, 12), (16, 20)])
+    else:
+        sd["per_pixel"] = rng.choice([4, 16, 24])
+    smin = rng.choice([2.0, 5.0, 10.0])
+    sc = dict(P=rng.choice([8000, 20000, 40000]), W=rng.choice([48, 96, 200]), H=rng.choice([32, 64, 120]),
+              sigma_min=smin, sigma_max=smin * rng.choice([2.0, 4.0]), seed=rng.randrange(1, 10**6), camera="orbit",
+              opacity_range=rng.choice([(0.05, 0.6), (0.01, 0.08), (0.004, 0.03)]))
+    return sc, sd
+
+
 def random_case(rng):
     mode = rng.choice([0, 0, 2, 2, 3, 3, 3, 3])
     sd = dict(mode=mode, order=rng.choice([0, 1, 2, 3]), rect=rng.random() < 0.5, tight=rng.random() < 0.5,
@@ -35,20 +52,26 @@ def main():
     ap.add_argument("--cases", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=600.0)
+    ap.add_argument("--heavy", action="store_true", help="dense scenes (overflowing blend logs, long lists) instead of the small ones")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     t0, done, bad = time.time(), 0, 0
     for i in range(args.cases):
         if time.time() - t0 > args.seconds:
             break
-        sc, sd = random_case(rng)
+        sc, sd = heavy_case(rng) if args.heavy else random_case(rng)
         scene = scenes.make_scene(**sc)
-        if rng.random() < 0.3:  # lower active SH degree / different scale modifier (Scene fields the API passes through)
+        if not args.heavy and rng.random() < 0.3:  # lower active SH degree / different scale modifier (Scene fields the API passes through)
             scene.sh_degree = rng.choice([0, 1, 2]) if scene.shs is not None else 0
-        if rng.random() < 0.3:
+        if not args.heavy and rng.random() < 0.3:
             scene.scale_modifier = rng.choice([0.5, 0.8, 1.7])
         try:
-            check_against_oracle(scene, settings_dict(**sd), backward=True)
+            if args.heavy:  # ~500-1000 blends per pixel: rounding of the transmittance product accumulates (seen: 2e-5), faint
+                # Gaussians (opacity at the 1/255 threshold) have gradients that hang on single threshold decisions
+                # and the 4x4 culling test is such a decision for a whole sub-tile (16 pixels x 3 channels at once)
+                check_against_oracle(scene, settings_dict(**sd), backward=True, img_tol=4e-5, grad_tol=2e-3, flip_grad_tol=5e-2, max_flipped=100)
+            else:
+                check_against_oracle(scene, settings_dict(**sd), backward=True)
         except Exception as e:  # noqa: BLE001
             bad += 1
             tb = traceback.extract_tb(e.__traceback__)[-1]
