@@ -48,16 +48,19 @@ __global__ void __launch_bounds__(256) depth_colormap_kernel(float* __restrict__
     if (idx >= N) return;
     const float mn = from_ordered(mm[0]), mx = from_ordered(mm[1]);
     const float T = out_color[N + idx];
-    const float x = fminf(fmaxf(out_color[idx] + T * mx, mn), mx) / (mx - mn);
+    // glm::clamp = min(max(x, lo), hi) with glm's `a < b ? b : a` selections: a NaN passes through (an empty frame has
+    // min == max, the reference divides 0 by 0 and returns NaN pixels; fminf / fmaxf would turn them into table entry 0)
+    auto clamp_glm = [](float v, float lo, float hi) { const float t = (v < lo) ? lo : v; return (hi < t) ? hi : t; };
+    const float x = clamp_glm(out_color[idx] + T * mx, mn, mx) / (mx - mn);
     // colormapTurbo: linear interpolation in the 256-entry table, every channel clamped to [0, 1]
-    const float interp = fminf(fmaxf(x * 255.0f, 0.0f), 255.0f);
+    const float interp = clamp_glm(x * 255.0f, 0.0f, 255.0f);
     const int lo = x > 0.0f ? (int)interp : 0;
     const int hi = lo >= 255 ? 255 : lo + 1;
     const float diff = interp - (float)lo;
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const float a = c_turbo[3 * lo + ch], b = c_turbo[3 * hi + ch];
-        out_color[ch * N + idx] = fminf(fmaxf(a + (b - a) * diff, 0.0f), 1.0f);
+        out_color[ch * N + idx] = clamp_glm(a + (b - a) * diff, 0.0f, 1.0f);
     }
 }
 

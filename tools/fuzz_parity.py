@@ -9,7 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "tests"), os.path.join(ROOT, "stopthepop-rasterization_amd"), ROOT):
     sys.path.insert(0, p)
 import conftest  # noqa: F401,E402  (path setup)
-from helpers import settings_dict  # noqa: E402
+import numpy as np  # noqa: E402
+from helpers import GpuRun, oracle_run, settings_dict  # noqa: E402
 from test_gpu_parity import check_against_oracle  # noqa: E402
 from diff_gaussian_rasterization import scenes  # noqa: E402
 
@@ -17,7 +18,7 @@ from diff_gaussian_rasterization import scenes  # noqa: E402
 def heavy_case(rng):
     """Dense scenes: hundreds to thousands of entries per tile, many blends per pixel (blend-log overflow, lists beyond the LDS
     sort capacity, several replay windows)."""
-    mode = rng.choice([2, 3, 3, 3])
+    mode = rng.choice([0, 2, 3, 3, 3])
     sd = dict(mode=mode, order=rng.choice([0, 1, 2, 3]), rect=rng.random() < 0.5, tight=rng.random() < 0.5,
               tbc=rng.random() < 0.5, h44=(mode == 3 and rng.random() < 0.6), lb=True, ewa=rng.random() < 0.2)
     if mode == 3:
@@ -66,12 +67,39 @@ def main():
         if not args.heavy and rng.random() < 0.3:
             scene.scale_modifier = rng.choice([0.5, 0.8, 1.7])
         try:
-            if args.heavy:  # ~500-1000 blends per pixel: rounding of the transmittance product accumulates (seen: 2e-5), faint
+            kind = rng.random()
+            if not args.heavy and kind < 0.12:    # depth visualisation (forward only, every sort mode incl. PPX_FULL)
+                sdv = dict(sd); sdv["mode"] = rng.choice([0, 1, 2, 3]) if scene.P <= 1500 and scene.W * scene.H <= 6400 else sd["mode"]
+                if sdv["mode"] != 3: sdv.pop("tile_2x2", None); sdv["h44"] = False
+                elif sd["mode"] != 3: sdv["per_pixel"], sdv["tile_2x2"] = 4, 8
+                if sdv["mode"] in (0, 1): sdv["per_pixel"] = 4
+                if sdv["mode"] == 2 and sdv.get("per_pixel", 4) not in (1, 2, 4, 8, 12, 16, 20, 24): sdv["per_pixel"] = 16
+                g = GpuRun(scene, settings_dict(**sdv), backward=False, render_depth=True)
+                f, _ = oracle_run(scene, settings_dict(**sdv), backward=False, render_depth=True)
+                # (an empty frame has min == max: 0/0 in the reference's normalisation, NaN on both sides)
+                assert np.array_equal(np.isnan(g.color), np.isnan(f.color)), "render_depth: NaN pattern"
+                dd = np.nan_to_num(np.abs(g.color.astype(np.float64) - f.color))
+                # (the normalisation divides by the frame's depth range: a nearly flat frame amplifies 1e-6 arbitrarily)
+                assert dd.max() <= 2e-3 or not (np.nanmax(f.color) - np.nanmin(f.color) >= 0.05), ("render_depth", float(dd.max()))
+            elif not args.heavy and kind < 0.30:  # inference forward (no blend log) of the same settings
+                check_against_oracle(scene, settings_dict(**sd), backward=False)
+            elif not args.heavy and kind < 0.40:  # a tile-row window (what a rank of the tile-row sharding renders)
+                gy = (scene.H + 15) // 16
+                y0 = rng.randrange(0, gy); y1 = rng.randrange(y0 + 1, gy + 1)
+                g = GpuRun(scene, settings_dict(**sd), backward=False, tile_rows=(y0, y1))
+                f, _ = oracle_run(scene, settings_dict(**sd), backward=False, tile_rows=(y0, y1))
+                rows = slice(16 * y0, min(16 * y1, scene.H))
+                dd = np.abs(g.color[:, rows].astype(np.float64) - f.color[:, rows])
+                assert g.num_rendered == f.num_rendered and dd.max() <= 1.0 / 255.0 + 1e-6 and int((dd > 2e-6).sum()) <= 6, ("tile rows", y0, y1, float(dd.max()))
+            elif args.heavy:  # ~500-1000 blends per pixel: rounding of the transmittance product accumulates (seen: 2e-5), faint
                 # Gaussians (opacity at the 1/255 threshold) have gradients that hang on single threshold decisions
                 # and the 4x4 culling test is such a decision for a whole sub-tile (16 pixels x 3 channels at once)
                 check_against_oracle(scene, settings_dict(**sd), backward=True, img_tol=4e-5, grad_tol=2e-3, flip_grad_tol=5e-2, max_flipped=100)
-            else:
-                check_against_oracle(scene, settings_dict(**sd), backward=True)
+            elif scene.P < 50:  # a handful of Gaussians: "relative to the largest entry" is relative to values that are themselves
+                # the result of cancellation (rotation gradient of a near-isotropic splat: seen 2e-3 with P = 1)
+                check_against_oracle(scene, settings_dict(**sd), backward=True, grad_tol=1e-2)
+            else:  # (flip_grad_tol: with opacities down to 0.004 a single flipped blend is a visible part of a Gaussian's gradient)
+                check_against_oracle(scene, settings_dict(**sd), backward=True, flip_grad_tol=2e-2)
         except Exception as e:  # noqa: BLE001
             bad += 1
             tb = traceback.extract_tb(e.__traceback__)[-1]
