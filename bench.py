@@ -118,6 +118,13 @@ def main():
     ap.add_argument("--force-shard", action="store_true", help="use the tile-row sharded path even with one rank (self-test of the exchange code)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the result of rank 0.  Libraries write there too (RCCL prints a five-line version
+    # banner through C stdio, which is flushed at exit, i.e. after our line): file descriptor 1 is pointed at stderr for
+    # the whole run and the JSON line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -301,7 +308,8 @@ def main():
             out["tile_shard"] = tile_probe
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, sdict, gy, fwd_only, args.cpu_rows)
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    os.close(result_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
