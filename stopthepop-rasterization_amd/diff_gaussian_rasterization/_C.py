@@ -245,6 +245,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                ctypes.c_float(scale_modifier), _ptr(ro_), _ptr(c3_), _ptr(vm_), _ptr(pm_), _ptr(inv_),
                                _ptr(cam_), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)),
                                _ptr(out_color), _ptr(radii), int(bool(debug)), _stream_ptr(dev))
+        for r in (geom, binning, img):
+            r.cb = None  # the callback object refers to its resizer: a cycle that would keep the buffers alive until a gc run
         if rc < 0:
             _raise_last(rc)
         rendered = rc
