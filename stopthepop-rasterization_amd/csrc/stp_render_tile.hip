@@ -321,18 +321,24 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(a.blend_log) + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
     int nrec = 0;
     const float4* const eF = a.entF + c.range.x;
+    const float4* const eCl = a.entC + c.range.x;
+    const float4* const eDl = a.entD + c.range.x;
 
     auto blend_one = [&]() {
         if (win.num == 0) return;
         bool ok;
         if constexpr (BACKWARD) ok = blend_backward(bp, a, c.px, c.py, win.id[0], win.store[0]);
         else {
+            // The forward windows do not carry alpha (two selects per slot and insertion less): it is evaluated again here,
+            // from the same entry record with the same instructions, hence to the same bits as when the entry passed the
+            // candidate test.
             const int pos = win.id[0];
-            const float4 colr = eF[pos];
+            const float4 colr = eF[pos], eCp = eCl[pos], eDp = eDl[pos];
             const float col[3] = {colr.x, colr.y, colr.z};
+            const float alpha0 = fminf(0.99f, eDp.w * exp_blend(blend_power(eCp.y - pxf, eCp.z - pyf, eDp)));
             const float T_before = fp.T;
-            ok = blend_forward_c(fp, col, win.store[0]);
-            if constexpr (DEPTHVIZ) { if (ok) depth_acc += win.depth[0] * win.store[0] * T_before; } // reference resorted_render.cuh:107
+            ok = blend_forward_c(fp, col, alpha0);
+            if constexpr (DEPTHVIZ) { if (ok) depth_acc += win.depth[0] * alpha0 * T_before; } // reference resorted_render.cuh:107
             if constexpr (RECORD) {
                 if (ok) {
                     if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (log_t)pos;
@@ -380,7 +386,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             if (alpha < ALPHA_THRESHOLD) continue;
             const float depth = depth_along_ray_ent(s_A[j], s_B[j], eCj, dir);
             if (depth < 0.0f) continue;
-            win.insert(depth, BACKWARD ? __float_as_int(eCj.w) : i * BLOCK + j, BACKWARD ? G : alpha);
+            win.insert(depth, BACKWARD ? __float_as_int(eCj.w) : i * BLOCK + j, BACKWARD ? G : 0.0f);
         }
     }
     if (!done)
