@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE ONLY -- see oracle/stp_oracle.h.  Imported by tests/, by
 __graft_entry__.smoke() and by bench.py's cpu_baseline leg; never by the product package.
-PARITY UNPINNED (no reference tests/fixtures exist, reference unbuildable here): see DESIGN.md.
+Pinned against the reference's own sources compiled for gfx950 (oracle/ref_build/, tests/golden/ref/): see stp_oracle.h.
 """
 from __future__ import annotations
 
@@ -184,8 +184,8 @@ def forward(*, bg, means3D, opacities, viewmatrix, projmatrix, inv_viewprojmatri
     return Frame(handle, out, radii, rc, inputs)
 
 
-def forward_scene(scene, settings: Optional[dict] = None, tile_rows=None, use_cov3D_precomp: bool = False,
-                  render_depth: bool = False) -> Frame:
+def forward_scene(scene, settings: Optional[dict] = None, tile_rows=None, cov3D_precomp=None,
+                  render_depth: bool = False, prefiltered: bool = False) -> Frame:
     """Convenience: run the oracle on a diff_gaussian_rasterization.scenes.Scene."""
     if render_depth:
         settings = {**(settings or {}), "_render_depth": True}
@@ -193,7 +193,8 @@ def forward_scene(scene, settings: Optional[dict] = None, tile_rows=None, use_co
                    projmatrix=scene.projmatrix, inv_viewprojmatrix=scene.inv_viewprojmatrix, campos=scene.campos,
                    tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, W=scene.W, H=scene.H, shs=scene.shs,
                    colors_precomp=scene.colors_precomp, scales=scene.scales, rotations=scene.rotations,
-                   sh_degree=scene.sh_degree, scale_modifier=scene.scale_modifier, settings=settings, tile_rows=tile_rows)
+                   cov3D_precomp=cov3D_precomp, sh_degree=scene.sh_degree, scale_modifier=scene.scale_modifier,
+                   settings=settings, tile_rows=tile_rows, prefiltered=prefiltered)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> np.ndarray:

@@ -1,7 +1,8 @@
 /*
  * oracle/stp_oracle.cpp -- CPU restatement of the StopThePop rasterizer hot path.
  *
- * TEST INFRASTRUCTURE ONLY (see stp_oracle.h).  PARITY UNPINNED (see stp_oracle.h).
+ * TEST INFRASTRUCTURE ONLY (see stp_oracle.h).  Pinned against the reference's own sources compiled for gfx950
+ * (oracle/ref_build/, tests/golden/ref/, tests/test_reference_golden.py); see stp_oracle.h for what that covers.
  *
  * This is our own from-scratch code.  It restates, stage by stage, what the reference computes
  * (citations "ref:" are file:line under /root/reference/cuda_rasterizer unless a path is given).
@@ -210,8 +211,19 @@ inline M3 compute_cov2D_full(V3 t, float fx, float fy, float tan_fovx, float tan
 // Canonical evaluation order (shared with the HIP kernels so that depth keys compare bit-for-bit):
 // every dot product is fma(c, z, fma(b, y, a*x)) with correctly rounded fused multiply-adds, the
 // reciprocal is the IEEE quotient 1/x.  (The CUDA reference lets nvcc contract these sums as it likes.)
+int g_ieee_depth = 0; // test-only switch "ieee_depth": the reference's expression with NO contraction (every product and
+                      // sum rounded separately, in the order stopthepop_common.cuh:47-51 writes them) -- what the
+                      // -ffp-contract=off build of the reference itself (oracle/_ref/libstp_ref_ieee.so) computes.
 inline float depth_along_ray(const float* pk, V3 v)
 {
+    if (g_ieee_depth) {
+        const float b0 = (pk[0] * v.x + pk[1] * v.y) + pk[2] * v.z;
+        const float b1 = (pk[1] * v.x + pk[4] * v.y) + pk[5] * v.z;
+        const float b2 = (pk[2] * v.x + pk[5] * v.y) + pk[6] * v.z;
+        const float n = (pk[8] * v.x + pk[9] * v.y) + pk[10] * v.z;
+        const float d = (b0 * v.x + b1 * v.y) + b2 * v.z;
+        return n * frcp(std::max(0.00001f, d));
+    }
     const float a0 = fmaf(pk[2], v.z, fmaf(pk[1], v.y, pk[0] * v.x));
     const float a1 = fmaf(pk[5], v.z, fmaf(pk[4], v.y, pk[1] * v.x));
     const float a2 = fmaf(pk[6], v.z, fmaf(pk[5], v.y, pk[2] * v.x));
@@ -1523,6 +1535,7 @@ int64_t orc_frame_array(const OrcFrame* f, const char* name, const void** data)
 void orc_set_flag(const char* name, int value)
 {
     if (name && std::string(name) == "ewa_exact_grad") g_ewa_exact_grad = value;
+    if (name && std::string(name) == "ieee_depth") g_ieee_depth = value;
 }
 
 int orc_num_threads(void)

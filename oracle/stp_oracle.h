@@ -6,12 +6,14 @@
  * as the checker / reported host baseline.  The product (libstp_raster.so) never links,
  * loads or falls back to it.
  *
- * PARITY UNPINNED: the reference repository ships no tests, golden vectors or fixtures for
- * this path, and its CUDA sources cannot be built in this image without writing stand-ins
- * for headers the image lacks (cuda_runtime.h, cooperative_groups.h, cub) -- see DESIGN.md.
- * The oracle is therefore a from-scratch restatement of the reference's algorithm, each
- * function citing the reference file:line it follows, cross-checked only by independent
- * means (float64 torch autograd reference, cross-mode consistency, finite differences).
+ * PARITY PIN: the reference ships no tests, golden vectors or fixtures for this path, and it is CUDA.  It is pinned
+ * against THE REFERENCE ITSELF compiled for gfx950: oracle/ref_build/build_ref.sh runs the ROCm image's own hipify-perl
+ * over the reference's cuda_rasterizer sources (where they lie under /root/reference) and compiles them with hipcc
+ * (-ffp-contract=off) into oracle/_ref/libstp_ref_ieee.so; tests/golden/ref/ holds that library's outputs (generated on
+ * an MI355X by tests/golden/make_ref_golden.py) and tests/test_reference_golden.py holds this oracle to them BIT FOR BIT
+ * in every integer / index result, per-Gaussian state array, sort key, sorted list and tile range, in every sort mode.
+ * What the pin is NOT: a run of the reference under nvcc on NVIDIA hardware (none exists here).  PER_PIXEL_FULL is not
+ * covered (the reference's kernel faults on gfx950).  See DESIGN.md section 5.
  */
 #ifndef STP_ORACLE_H_INCLUDED
 #define STP_ORACLE_H_INCLUDED
@@ -86,7 +88,9 @@ int64_t orc_frame_array(const OrcFrame* frame, const char* name, const void** da
 int orc_frame_num_rendered(const OrcFrame* frame);
 
 /* Test-only switches.  "ewa_exact_grad"=1: use the mathematically exact Mip-Splatting scaling
-   gradient instead of the reference's (see stp_oracle.cpp backward_preprocess). */
+   gradient instead of the reference's (see stp_oracle.cpp backward_preprocess).
+   "ieee_depth"=1: evaluate depthAlongRay without fused multiply-adds, as the -ffp-contract=off build of the
+   reference itself does (oracle/_ref/libstp_ref_ieee.so); default 0 = the fma order shared with the HIP kernels. */
 void orc_set_flag(const char* name, int value);
 
 /* Number of OpenMP threads the oracle will use (for bench.py's cpu_baseline.cores). */

@@ -134,8 +134,11 @@ ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* to
     s.tile_counts = c.take<uint32_t>(T, &off); note("tile_counts", off, T);
     s.tile_cursor = c.take<uint32_t>(T, &off); note("tile_cursor", off, T);
     s.bin_total = c.take<uint32_t>(2, &off); note("bin_total", off, 2);
-    if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 4 bytes per pixel
-        s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
+    // tile_flags is ALWAYS there: a forward that records no log marks every tile "no valid log" (0xFFFFFFFF), so a backward
+    // that is (wrongly) told a log exists -- e.g. after a render_depth forward -- replays nothing and re-sorts every tile
+    // instead of reading a log that was never allocated.
+    s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
+    if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 2 bytes per pixel
         s.blend_log = c.take<uint32_t>(T * 256 * 256 / 2, &off); note("blend_log", off, T * 256 * 256); // T x 4 waves x 256 records x 64 lanes, 2 B each
     }
     if (total) *total = c.total();
@@ -359,7 +362,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
     ImageState img = carve_image(img_ptr, N, T, with_log, nullptr);
-    if (with_log) STP_TRY(hipMemsetAsync(img.tile_flags, 0, T * sizeof(uint32_t), st), "memset tile flags");
+    STP_TRY(hipMemsetAsync(img.tile_flags, with_log ? 0 : 0xFF, T * sizeof(uint32_t), st), "memset tile flags");
 
     // How the (tile, depth) order is established:
     //   default           device-wide radix sort on the tile bits only (two passes), then the tile's own workgroup sorts its

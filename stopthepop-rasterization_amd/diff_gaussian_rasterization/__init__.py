@@ -49,9 +49,11 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings):
         rs = raster_settings
         sdict = rs.settings.to_dict()
-        if any(ctx.needs_input_grad):
+        if any(ctx.needs_input_grad) and not rs.render_depth:
             # a backward can follow: let the hierarchical forward record each pixel's blend order so that the
-            # backward replays it instead of re-sorting (extension of ours; ignored by the other sort modes)
+            # backward replays it instead of re-sorting (extension of ours; ignored by the other sort modes).
+            # Not with render_depth: the depth-visualisation forward records no log, and a backward through it
+            # (meaningless in the reference too, but memory-safe there) must take the re-sorting path.
             sdict["_record_blend_log"] = True
         ctx.settings_dict = sdict
         # positional layout of _C.rasterize_gaussians (22 arguments)

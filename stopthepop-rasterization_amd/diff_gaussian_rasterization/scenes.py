@@ -158,6 +158,21 @@ def make_scene(P: int, W: int, H: int, sigma_min: float, sigma_max: float, seed:
                  meta=dict(seed=seed, sigma=(sigma_min, sigma_max), camera=camera))
 
 
+def covariance_from_scale_rotation(scene: "Scene") -> np.ndarray:
+    """(P,6) float32 world-space covariances [xx, xy, xz, yy, yz, zz] = R diag((mod*s)^2) R^T of the scene's scales and
+    rotations, evaluated in float64 and rounded: a valid `cov3D_precomp` INPUT for the same Gaussians (ref:
+    forward_common.h:149-183 computes the same matrix in fp32; as an input, bit equality with that is not needed)."""
+    q = scene.rotations.astype(np.float64)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                  2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                  2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], axis=1).reshape(-1, 3, 3)
+    s2 = (scene.scale_modifier * scene.scales.astype(np.float64)) ** 2
+    S = np.einsum("pij,pj,pkj->pik", R, s2, R)
+    return np.ascontiguousarray(np.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], axis=1),
+                                dtype=np.float32)
+
+
 # BASELINE.json configs made concrete (SURVEY.md section 8(d) table)
 _CONFIGS = {
     "C1": dict(P=1_000, W=256, H=256, sigma_min=1.0, sigma_max=12.0, seed=1),

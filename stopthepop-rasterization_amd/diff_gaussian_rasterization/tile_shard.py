@@ -112,7 +112,7 @@ class _ShardedRasterize(torch.autograd.Function):
         dist, rank, world, parts, to_all = shard
         sdict = dict(rs.settings.to_dict())
         sdict["_tile_rows"] = parts[rank]
-        if any(ctx.needs_input_grad):
+        if any(ctx.needs_input_grad) and not rs.render_depth:
             sdict["_record_blend_log"] = True
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,

@@ -36,7 +36,9 @@ def ext_settings(d):
 class GpuRun:
     """Runs one scene through the product's public API on cuda:0 and keeps what the tests inspect."""
 
-    def __init__(self, scene, sdict, backward=True, device="cuda:0", tile_rows=None, debug=False, render_depth=False):
+    def __init__(self, scene, sdict, backward=True, device="cuda:0", tile_rows=None, debug=False, render_depth=False,
+                 cov3D_precomp=None, prefiltered=False):
+        """cov3D_precomp: (P,6) array -> passed INSTEAD of scales/rotations (ref: __init__.py:286-289 allows exactly one)."""
         import torch
         import diff_gaussian_rasterization as dgr
         from diff_gaussian_rasterization import _C
@@ -47,6 +49,9 @@ class GpuRun:
         self.scales, self.rots = t(scene.scales, True), t(scene.rotations, True)
         self.shs, self.colors = t(scene.shs, True), t(scene.colors_precomp, True)
         self.means2D = torch.zeros_like(self.means3D, requires_grad=backward)
+        self.cov3D = t(cov3D_precomp, True)
+        if self.cov3D is not None:
+            self.scales = self.rots = None
         es = ext_settings(sdict)
         if tile_rows is not None:
             # tile-row window rides along in the dict through a private key (see _C.settings_from_dict)
@@ -56,11 +61,11 @@ class GpuRun:
             image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
             scale_modifier=scene.scale_modifier, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix),
             inv_viewprojmatrix=t(scene.inv_viewprojmatrix), sh_degree=scene.sh_degree, campos=t(scene.campos),
-            prefiltered=False, settings=es, render_depth=render_depth, debug=debug)
+            prefiltered=prefiltered, settings=es, render_depth=render_depth, debug=debug)
         self.rs = rs
         rast = dgr.GaussianRasterizer(rs)
         color, radii = rast(self.means3D, self.means2D, self.opac, shs=self.shs, colors_precomp=self.colors,
-                            scales=self.scales, rotations=self.rots)
+                            scales=self.scales, rotations=self.rots, cov3D_precomp=self.cov3D)
         self.color_t = color
         self.color = color.detach().cpu().numpy()
         self.radii = radii.cpu().numpy()
@@ -72,9 +77,9 @@ class GpuRun:
         else:  # forward-only run (no tensor requires grad): fetch the scratch buffers with a direct _C call
             empty = torch.Tensor([])
             e = lambda x: empty if x is None else x
-            out = _C.rasterize_gaussians(rs.bg, self.means3D, e(self.colors), self.opac, self.scales, self.rots, rs.scale_modifier,
-                                         empty, rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy,
-                                         rs.image_height, rs.image_width, e(self.shs), rs.sh_degree, rs.campos, False,
+            out = _C.rasterize_gaussians(rs.bg, self.means3D, e(self.colors), self.opac, e(self.scales), e(self.rots), rs.scale_modifier,
+                                         e(self.cov3D), rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy,
+                                         rs.image_height, rs.image_width, e(self.shs), rs.sh_degree, rs.campos, prefiltered,
                                          es.to_dict(), render_depth, debug)
             self.num_rendered, color2 = out[0], out[1]
             assert torch.equal(torch.nan_to_num(color2, nan=-1.0), torch.nan_to_num(color, nan=-1.0))  # (render_depth of an empty frame is NaN, as in the reference)
@@ -87,7 +92,7 @@ class GpuRun:
             g = lambda x: None if x is None or x.grad is None else x.grad.detach().cpu().numpy()
             self.grads = dict(dL_dmeans3D=g(self.means3D), dL_dmeans2D=g(self.means2D), dL_dopacity=g(self.opac),
                               dL_dscales=g(self.scales), dL_drotations=g(self.rots), dL_dsh=g(self.shs),
-                              dL_dcolors=g(self.colors))
+                              dL_dcolors=g(self.colors), dL_dcov3D=g(self.cov3D))
 
     def geom_array(self, name):
         return self._C.geometry_array(self.geom, self.scene.P, self.sdict, name).cpu().numpy()
@@ -100,8 +105,8 @@ class GpuRun:
         return self._C.image_array(self.img, self.scene.W, self.scene.H, name).cpu().numpy()
 
 
-def oracle_run(scene, sdict, backward=True, tile_rows=None, render_depth=False):
+def oracle_run(scene, sdict, backward=True, tile_rows=None, render_depth=False, cov3D_precomp=None):
     from oracle import oracle as orc
-    f = orc.forward_scene(scene, sdict, tile_rows=tile_rows, render_depth=render_depth)
+    f = orc.forward_scene(scene, sdict, tile_rows=tile_rows, render_depth=render_depth, cov3D_precomp=cov3D_precomp)
     g = f.backward(scene.dL_dout) if backward else None
     return f, g

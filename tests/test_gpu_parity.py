@@ -246,6 +246,36 @@ def test_forward_without_grad_records_nothing():
     assert np.array_equal(g.color, g2.color)
 
 
+@pytest.mark.parametrize("sd", [settings_dict(3, h44=True), settings_dict(2, per_pixel=16)], ids=["hier", "kbuffer16"])
+def test_backward_after_a_render_depth_forward_is_memory_safe(sd):
+    """The depth-visualisation forward records no blend log.  (1) Through the public API the backward that follows takes
+    the re-sorting path and gives the gradients of the same frame rendered without the log.  (2) At the _C level, a
+    backward that is WRONGLY told a log exists (what the autograd function used to do) finds every tile marked "no valid
+    log" and re-sorts them all: same gradients, no read of a log that was never allocated."""
+    sc = scenes.make_scene(**DENSE)
+    g = GpuRun(sc, sd, backward=True, render_depth=True)      # (1) must not fault; gradients are finite
+    assert all(np.isfinite(v).all() for v in g.grads.values() if v is not None)
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.tensor(a, device=dev)
+    empty = torch.Tensor([])
+    fwd = lambda d, depth: _C.rasterize_gaussians(t(sc.bg), t(sc.means3D), empty, t(sc.opacities), t(sc.scales), t(sc.rotations), 1.0, empty,
+                                                  t(sc.viewmatrix), t(sc.projmatrix), t(sc.inv_viewprojmatrix), sc.tanfovx, sc.tanfovy,
+                                                  sc.H, sc.W, t(sc.shs), 3, t(sc.campos), False, d, depth, False)
+    def bwd(out, d):
+        R, color, radii, geom, binning, img = out
+        return _C.rasterize_gaussians_backward(t(sc.bg), t(sc.means3D), radii, t(sc.opacities), empty, t(sc.scales), t(sc.rotations), 1.0,
+                                               empty, t(sc.viewmatrix), t(sc.projmatrix), t(sc.inv_viewprojmatrix), sc.tanfovx,
+                                               sc.tanfovy, color, t(sc.dL_dout), t(sc.shs), 3, t(sc.campos), geom, R, binning, img, d, False)
+    out = fwd(sd, True)                                          # depth forward: no log in the image buffer
+    lied = bwd(out, {**sd, "_record_blend_log": True})           # (2)
+    honest = bwd(fwd(sd, True), sd)
+    for a, b in zip(lied, honest):
+        if a is not None and a.numel():
+            assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["c1_global", "dense_hier_full", "dense_kbuffer"])
 def test_golden_fixtures(name):
     from golden.make_golden import CASES

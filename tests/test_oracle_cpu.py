@@ -1,7 +1,7 @@
 """CPU tests (-m "not gpu") of the oracle itself: the independent float64 torch reference pins its value and
 gradient maths, cross-mode consistency pins the resorting machinery, golden fixtures pin it against
-regressions.  NOTE: the reference ships no tests/fixtures and cannot be built here, so none of these
-pins comes from the reference itself ("parity unpinned")."""
+regressions.  These pins are independent of the reference; the pin to the reference itself (its own sources compiled
+for gfx950) is tests/test_reference_golden.py."""
 import os
 
 import numpy as np

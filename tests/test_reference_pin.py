@@ -1,0 +1,185 @@
+"""GPU tests (-m gpu): the HIP product, through its public drop-in API, against THE REFERENCE ITSELF.
+
+Two sources of reference results:
+  * tests/golden/ref/*.npz -- outputs of the reference's own kernels (hipify-perl + hipcc -ffp-contract=off build,
+    oracle/ref_build/build_ref.sh), generated once on an MI355X and committed as data;
+  * oracle/_ref/libstp_ref{,_ieee}.so -- the same reference build, run LIVE next to the product on fresh seeds
+    (built in the development container where /root/reference exists; travels to the GPU box like our own .so).
+
+Tolerances.  The reference's results are only defined up to floating-point contraction (nvcc / hipcc decide where a*b+c
+fuses).  Its own two builds (contract off / hipcc default) differ from each other by up to 7e-3 in the image (85 dB)
+in dense scenes (profiles/r02_reference_pin.md), because ulp-level differences in depthAlongRay swap neighbours in the
+per-pixel order.  The product is held to much less than that against the IEEE build:
+  * integers that do not depend on depthAlongRay (num_rendered, radii, tile counts, offsets, ranges; keys and the
+    sorted list for Z / DISTANCE order): exact;
+  * per-tile-depth keys: tile ids exact, depths within 64 ulp (512 against the hipcc-default build, whose own contraction
+    differs again), sorted list equal up to 2e-3 of its entries;
+  * image: PSNR >= 60 dB (north_star) and <= 2e-6 outside at most 2 % of the values (a neighbour swap in a GLOBAL-mode
+    list moves every pixel both splats cover: 130 of 9216 values of the 64x48 fixture `gold_ptd_max`, by <= 6e-4);
+  * gradients: <= 1e-4 of the largest entry when no pixel moved, 2e-2 otherwise.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from helpers import FULL_STP, GpuRun, max_abs, oracle_run, psnr, settings_dict
+from diff_gaussian_rasterization import scenes
+from oracle import reference as ref
+from test_reference_golden import FIXTURES, _rel, _ulps, load_case
+
+pytestmark = pytest.mark.gpu
+
+PRODUCT_GRADS = ("dL_dmeans2D", "dL_dopacity", "dL_dcolors", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations")
+
+
+def compare_product_with_reference(g, sc, sd, r_num_rendered, r_radii, r_state, r_keys, r_list, r_ranges, r_color, r_grads,
+                                   c3=None, strict_state=True):
+    order = sd["sort_settings"]["sort_order"]
+    tight = sd["culling_settings"]["tight_opacity_bounding"]
+    assert g.num_rendered == r_num_rendered
+    assert np.array_equal(g.radii, r_radii)
+    vis = r_radii > 0
+    assert np.array_equal(g.geom_array("tiles_touched").view(np.uint32), r_state["tiles_touched"])
+    assert np.array_equal(g.geom_array("point_offsets").view(np.uint32), r_state["point_offsets"])
+    for nm, per in (("depths", 1), ("means2D", 2), ("conic_opacity", 4), ("cov3D", 6)):
+        if nm == "cov3D" and c3 is not None:
+            continue
+        a, b = g.geom_array(nm).reshape(-1, per)[vis], r_state[nm].reshape(-1, per)[vis]
+        if strict_state:
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), nm
+        else:
+            assert _rel(a, b) < 2e-6, nm
+    if r_num_rendered:
+        ka, kb = g.binning_array("keys"), r_keys
+        assert np.array_equal(ka >> np.uint64(32), kb >> np.uint64(32))
+        assert np.array_equal(g.image_array("ranges").view(np.uint32).reshape(-1)[:r_ranges.size], r_ranges)
+        if order < 2 and strict_state and not tight:
+            assert np.array_equal(ka, kb)
+            assert np.array_equal(g.binning_array("point_list"), r_list)
+        else:
+            da = (ka & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32)
+            db = (kb & np.uint64(0xFFFFFFFF)).astype(np.uint32).view(np.float32)
+            assert _ulps(np.sort(da), np.sort(db)) <= (64 if strict_state else 512)   # (seen: 68 against the hipcc-default build)
+            swapped = g.binning_array("point_list") != r_list
+            assert int(swapped.sum()) <= max(4, int(2e-3 * swapped.size))
+    d = np.abs(g.color.astype(np.float64) - r_color.astype(np.float64))
+    moved = int((d > 2e-6).sum())
+    assert moved <= 0.02 * d.size, moved
+    assert psnr(g.color, r_color) >= 60.0
+    if r_grads is not None and g.grads is not None:
+        tol = 1e-4 if moved == 0 else 2e-2
+        for k in PRODUCT_GRADS:
+            a, b = g.grads.get(k), r_grads.get(k)
+            if a is None or b is None or b.size == 0:
+                continue
+            if k == "dL_dmeans2D":
+                a, b = a[:, :2], b[:, :2]
+            assert _rel(a, b) <= tol, k
+    return moved
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_product_against_reference_fixtures(path):
+    z, sc, sd, c3 = load_case(path)
+    depth = bool(z["render_depth"])
+    g = GpuRun(sc, sd, backward=not depth, cov3D_precomp=c3, render_depth=depth)
+    if depth:   # DebugVisualization::Depth: colormapped image only
+        assert g.num_rendered == int(z["num_rendered"]) and np.array_equal(g.radii, z["radii"])
+        assert max_abs(g.color, z["color"]) <= 2e-3 and psnr(g.color, z["color"]) >= 60.0
+        return
+    state = {k[6:]: z[k] for k in z.files if k.startswith("state_")}
+    grads = {k[5:]: z[k] for k in z.files if k.startswith("grad_")}
+    compare_product_with_reference(g, sc, sd, int(z["num_rendered"]), z["radii"], state, z["keys"], z["point_list"], z["ranges"],
+                                   z["color"], grads, c3=c3)
+
+
+LIVE = pytest.mark.skipif(not (ref.available("ieee") and ref.available("fast")),
+                          reason="oracle/_ref not built (oracle/ref_build/build_ref.sh needs /root/reference)")
+
+
+@LIVE
+@pytest.mark.parametrize("variant", ["ieee", "fast"])
+@pytest.mark.parametrize("name,sd", [
+    ("global", settings_dict(0)), ("kbuffer16", settings_dict(2, per_pixel=16)), ("hier", settings_dict(3)),
+    ("hier_cull_h8_m12", settings_dict(3, per_pixel=8, tile_2x2=12, h44=True)), ("full_stp", settings_dict(**FULL_STP)),
+    ("full_stp_ewa", settings_dict(**{**FULL_STP, "ewa": True}))])
+def test_product_against_the_live_reference(name, sd, variant):
+    """Fresh seed, denser scene (~700 entries per tile), both builds of the reference.  Against the hipcc-default
+    build the per-Gaussian state is compared at 2e-6 instead of bit-for-bit (that build contracts where it likes)."""
+    sc = scenes.make_scene(P=6000, W=96, H=80, sigma_min=2.0, sigma_max=14.0, seed=77, camera="orbit")
+    rf = ref.forward_scene(sc, sd, variant=variant)
+    rg = rf.backward(sc.dL_dout)
+    g = GpuRun(sc, sd, backward=True)
+    state = {nm: rf.array(nm) for nm in ("tiles_touched", "point_offsets", "depths", "means2D", "conic_opacity", "cov3D")}
+    strict = variant == "ieee"
+    if not strict:   # the default build's own contraction moves radii / tile counts of a few Gaussians by one
+        same = (g.radii == rf.radii).mean()
+        assert same >= 0.999
+        if g.num_rendered != rf.num_rendered or not np.array_equal(g.radii, rf.radii):
+            assert abs(g.num_rendered - rf.num_rendered) <= 0.001 * rf.num_rendered
+            assert psnr(g.color, rf.color) >= 60.0
+            return
+    compare_product_with_reference(g, sc, sd, rf.num_rendered, rf.radii, state, rf.array("keys"), rf.array("point_list"),
+                                   rf.array("ranges"), rf.color, rg, strict_state=strict)
+
+
+@LIVE
+def test_oracle_against_the_live_reference_on_a_fresh_seed():
+    """The CPU oracle (ieee_depth switch) reproduces the IEEE build of the reference bit for bit in everything integer,
+    on a scene that is not among the fixtures."""
+    from oracle import oracle as orc
+    sc = scenes.make_scene(P=4000, W=80, H=64, sigma_min=1.5, sigma_max=12.0, seed=78, camera="orbit")
+    for sd in (settings_dict(3, h44=True), settings_dict(**{**FULL_STP, "lb": False}), settings_dict(2, per_pixel=8)):
+        rf = ref.forward_scene(sc, sd, variant="ieee")
+        orc.set_flag("ieee_depth", 1)
+        try:
+            of = orc.forward_scene(sc, sd)
+        finally:
+            orc.set_flag("ieee_depth", 0)
+        assert of.num_rendered == rf.num_rendered and np.array_equal(of.radii, rf.radii)
+        for nm in ("keys", "point_list", "ranges", "tiles_touched", "point_offsets"):
+            assert np.array_equal(of.array(nm), rf.array(nm)), nm
+        assert max_abs(of.color, rf.color) <= 2e-6
+
+
+# ---- cov3D_precomp / prefiltered through the product's public API (ref: forward.cu:126-135, backward.cu:428-433,
+# ---- rasterizer_impl.cu:500, auxiliary.h:228-232)
+
+def test_cov3D_precomp_global_mode_against_oracle_incl_dL_dcov3D():
+    sc = scenes.make_scene(P=3000, W=128, H=96, sigma_min=1.0, sigma_max=10.0, seed=41, camera="orbit")
+    c3 = scenes.covariance_from_scale_rotation(sc)
+    for sd in (settings_dict(0), settings_dict(0, ewa=True), settings_dict(0, order=1, rect=True, tight=True, tbc=True)):
+        g = GpuRun(sc, sd, backward=True, cov3D_precomp=c3)
+        f, og = oracle_run(sc, sd, backward=True, cov3D_precomp=c3)
+        assert g.num_rendered == f.num_rendered and np.array_equal(g.radii, f.radii)
+        assert np.array_equal(g.binning_array("point_list"), f.array("point_list"))
+        assert max_abs(g.color, f.color) <= 2e-6
+        assert g.grads["dL_dscales"] is None and g.grads["dL_drotations"] is None
+        for k in ("dL_dcov3D", "dL_dmeans3D", "dL_dopacity", "dL_dsh"):
+            assert _rel(g.grads[k], og[k]) <= 1e-4, k
+        assert float(np.abs(og["dL_dcov3D"]).max()) > 0
+
+
+def test_cov3D_precomp_without_scales_raises_in_sorted_modes():
+    """Sorted modes build Sigma^-1 from scales + rotations (ref: forward.cu:208-220 dereferences them)."""
+    sc = scenes.make_scene(P=200, W=48, H=32, sigma_min=1.0, sigma_max=6.0, seed=42)
+    c3 = scenes.covariance_from_scale_rotation(sc)
+    for sd in (settings_dict(3), settings_dict(2, per_pixel=16), settings_dict(1), settings_dict(0, order=2)):
+        with pytest.raises(RuntimeError, match="sorted modes need scales and rotations"):
+            GpuRun(sc, sd, backward=False, cov3D_precomp=c3)
+
+
+def test_prefiltered():
+    """prefiltered=True promises that no Gaussian fails the near-plane test; a clean scene renders identically, a
+    violating one is an error (the reference prints this text and traps the device, auxiliary.h:228-232)."""
+    sc = scenes.make_scene(P=500, W=64, H=48, sigma_min=1.0, sigma_max=6.0, seed=43)      # z in [2, 12]: all in front
+    a = GpuRun(sc, settings_dict(3), backward=False)
+    b = GpuRun(sc, settings_dict(3), backward=False, prefiltered=True)
+    assert np.array_equal(a.color, b.color) and np.array_equal(a.radii, b.radii)
+    sc.means3D[7, 2] = 0.1                                                                 # behind the 0.2 near plane
+    GpuRun(sc, settings_dict(3), backward=False)                                           # fine without the promise
+    with pytest.raises(RuntimeError, match="Point is filtered although prefiltered is set"):
+        GpuRun(sc, settings_dict(3), backward=False, prefiltered=True)
