@@ -58,27 +58,42 @@ def settings_for(variant: str, workload: str):
     return es
 
 
-def algorithmic_bytes(P, P_v, R, N, T, M, S, mode_hier, K, E, sh, B=0):
-    """Compulsory HBM traffic per stage, bytes: every array element the stage must read or
-    write counted once.  P Gaussians, P_v visible, R tile-list entries, N pixels, T tiles, M SH coefficients,
-    S = 1 if the mode needs Sigma^-1, K/E = per-tile-depth / culling extras of duplicate, B = blended
-    (pixel, entry) pairs recorded in the blend log (hierarchical training forward; 0 otherwise)."""
+def survey_bytes(P, P_v, R, N, T, M, S, mode, K, E, sh, ewa):
+    """ALGORITHMIC bytes per stage, SURVEY.md section 8(d) verbatim (the compulsory traffic of the REFERENCE's data flow;
+    the figure `roofline.achieved` is priced on).  P Gaussians, P_v visible, R tile-list entries, N pixels, T tiles, M SH
+    coefficients, S = 1 if the mode needs Sigma^-1, K = per-tile depth order, E = TBC or PTD_MAX, sh = SH used."""
+    hier, glob = mode == 3, mode == 0
+    b = {}
+    b["preprocess"] = P * (44 + 8) + P_v * (12 * M * sh + 60 + 48 * S + 15 * sh)
+    b["scan"] = 8 * P
+    b["duplicate"] = 8 * P + P_v * (20 + 16 * E + 48 * K) + 12 * R
+    b["sort"] = 24 * R
+    b["ranges"] = 8 * R + 16 * T
+    b["render_fwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (0 if hier else 4))
+    b["zero_fill"] = P * (108 + 12 * M)
+    b["render_bwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (4 if glob else 12)) + 88 * P_v
+    b["bwd_cov2D"] = 4 * P + P_v * (52 + 36) + (8 * P_v if ewa else 0)
+    b["bwd_preprocess"] = 4 * P + P_v * (36 + sh * (12 * M + 15) + 52) + P_v * (12 + sh * 12 * M + 28)
+    return b
+
+
+def design_bytes(P, P_v, R, N, T, M, S, mode, K, E, sh, B=0):
+    """Bytes of OUR data flow per stage: the same stages plus what this design adds on purpose -- the
+    list-ordered 80-byte entry records and their gather, the packed 64-byte Gaussian line, the 2-byte blend-log record of
+    every blended (pixel, entry) pair (B), the 64-byte gradient records.  Reported beside the algorithmic bytes; never used
+    for `roofline.achieved`."""
+    hier = mode == 3
     b = {}
     b["preprocess"] = P * (44 + 8) + P_v * (12 * M * sh + 60 + (48 + 64) * S + 15 * sh)
     b["scan"] = 8 * P
     b["duplicate"] = 8 * P + P_v * (20 + 16 * E + 48 * K) + 12 * R
     b["sort"] = 24 * R
     b["ranges"] = 8 * R + 16 * T
-    # per-pixel-sort modes (S): the list-ordered entry records (80 B each) are gathered once (id + the Gaussian's packed
-    # 64-byte line + colour in, record out) and are what the render kernels read; GLOBAL reads by Gaussian id
     b["gather"] = R * (4 + 64 + 12 + 80) if S else 0
     per_entry_fwd = 80 if S else (4 + 24 + 12)
-    # forward render: every list entry's data once per tile, the pixel outputs, and (recording forward) the 2-byte log
-    # record of every blended pair + n_contrib + tile flags
-    b["render_fwd"] = 8 * T + R * per_entry_fwd + N * (16 + (0 if mode_hier else 4)) + (2 * B + 4 * N + 4 * T if B else 0)
+    b["render_fwd"] = 8 * T + R * per_entry_fwd + N * (16 + (0 if hier else 4)) + (2 * B + 4 * N + 4 * T if B else 0)
     b["zero_fill"] = P * 64
-    if B:   # replay backward: the log, the blended entries' records (mean + id, conic/opacity, colour: 48 B), the pixel state,
-            # and one read-modify-write of every visible Gaussian's 64-byte gradient record
+    if B:
         b["render_bwd"] = 8 * T + 2 * B + R * 48 + N * (4 + 4 + 12 + 12) + 128 * P_v
     else:
         b["render_bwd"] = 8 * T + R * (4 + 24 + 48 * S + 12) + N * (16 + (12 if S else 4)) + 128 * P_v
@@ -86,17 +101,31 @@ def algorithmic_bytes(P, P_v, R, N, T, M, S, mode_hier, K, E, sh, B=0):
     return b
 
 
-def measured_traffic(kernel: str, workload: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
-    tools/profile.sh + tools/traffic_json.py on the GPU box: FETCH_SIZE and WRITE_SIZE collected in separate passes,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when no profile of this kernel exists."""
+def csrc_sha256():
+    """Hash of the kernel sources: profiles/traffic.json is stamped with it, and a stale profile is not quoted."""
+    import hashlib
+    d = os.path.join(ROOT, "stopthepop-rasterization_amd", "csrc")
+    h = hashlib.sha256()
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".inc")) or fn == "Makefile":
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()
+
+
+def profile_entry(kernel: str, workload: str):
+    """(entry, note) for `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by tools/profile.sh +
+    tools/traffic_json.py on the GPU box: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; SQ counters of pass 1).  The file carries the hash of csrc/ it was taken on:
+    when the kernels have changed since, nothing is quoted (entry None, note says so)."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
             t = json.load(f)
-        e = t.get(workload, {}).get(kernel)
-        return int(e["hbm_bytes_per_launch"]) if e else None
-    except (OSError, ValueError, KeyError):
-        return None
+    except (OSError, ValueError):
+        return None, "no profiles/traffic.json"
+    if t.get("_csrc_sha256") != csrc_sha256():
+        return None, "profiles/traffic.json was taken on different kernel sources (csrc hash mismatch): not quoted"
+    e = t.get(workload, {}).get(kernel)
+    return (e, t.get("_taken", "")) if e else (None, f"no PMC profile of {kernel} for {workload}")
 
 
 def main():
@@ -261,12 +290,10 @@ def main():
             tile_probe = {"error": repr(ex)[:300]}
 
     if rank == 0:
-        # measured sizes for the byte model
+        # measured sizes for the byte models
         radii = state["radii"]
         P = scene.P
         P_v = int((radii > 0).sum().item())
-        fn = state["color"].grad_fn
-        R = int(getattr(fn, "num_rendered", 0)) if fn is not None else 0
         N = scene.W * scene.H
         T = ((scene.W + 15) // 16) * gy
         mode = int(sdict["sort_settings"]["sort_mode"])
@@ -274,31 +301,52 @@ def main():
         S = 1 if (mode != 0 or order >= 2) else 0
         Kf = 1 if order >= 2 else 0
         E = 1 if (sdict["culling_settings"]["tile_based_culling"] or order == 3) else 0
-        # blended pairs recorded by the training forward (one untimed forward; the timed graphs are gone)
-        B = 0
+        ewa = bool(sdict["proper_ewa_scaling"])
         head, mid = int(sdict["sort_settings"]["queue_sizes"]["per_pixel"]), int(sdict["sort_settings"]["queue_sizes"]["tile_2x2"])
         cull = bool(sdict["culling_settings"]["hierarchical_4x4_culling"])
         recording = mode in (2, 3) and not fwd_only and os.environ.get("STP_BACKWARD", "replay") != "resort" and not sharded
+        # R (tile-list entries) and B (blended (pixel, entry) pairs) from ONE extra untimed forward through _C directly: a
+        # forward-only run has no grad_fn to ask, and the timed graphs are gone
+        empty = torch.Tensor([])
+        d1 = dict(sdict)
         if recording:
-            c2, _ = raster(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
-            B = int(_C.image_array(c2.grad_fn.saved_tensors[11], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256).sum().item())
-            del c2
-        bts = algorithmic_bytes(P, P_v, R, N, T, 16, S, mode == 3, Kf, E, 1, B)
+            d1["_record_blend_log"] = True
+        o1 = _C.rasterize_gaussians(rs.bg, means3D.detach(), empty, opac.detach(), scales.detach(), rots.detach(), 1.0, empty,
+                                    rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                    rs.image_width, shs.detach(), rs.sh_degree, rs.campos, False, d1, False, False)
+        R = int(o1[0])
+        B = 0
+        if recording or mode in (0, 2):   # n_contrib = blends per pixel (recording forwards), list positions visited (GLOBAL / k-buffer)
+            B = int(_C.image_array(o1[5], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256 if recording else 1 << 30).sum().item())
+        _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
+        del o1
+        M = 16
+        alg = survey_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, ewa)
+        des = design_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, B if recording else 0)
         dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
-        dom_bytes = bts["render_bwd"] if dom == "BwdRender" else bts["render_fwd"]
+        dom_key = "render_bwd" if dom == "BwdRender" else "render_fwd"
         dom_ms = stage_ms.get(dom, float("nan"))
-        achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
+        achieved = alg[dom_key] / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
         if mode == 3:
-            kname = ("render_hier_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1>") if dom == "BwdRender" \
+            kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1>") if dom == "BwdRender" \
                 else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}>"
+        elif mode == 2:
+            kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
+                f"render_kbuffer_kernel<{head}, {1 if dom == 'BwdRender' else (2 if recording else 0)}>"
         else:
-            kname = {0: "render_global", 1: "render_full", 2: "render_kbuffer"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
-            if mode == 2:
-                kname = "render_hier_replay_kernel" if (dom == "BwdRender" and recording) else \
-                    f"render_kbuffer_kernel<{head}, {1 if dom == 'BwdRender' else (2 if recording else 0)}>"
-        traffic = measured_traffic(kname, f"{args.workload}-{args.variant}")
-        fwd_bytes = sum(bts[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "gather", "render_fwd"))
-        bwd_bytes = sum(bts[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess"))
+            kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
+        prof, prof_note = profile_entry(kname, f"{args.workload}-{args.variant}")
+        fwd_keys, bwd_keys = ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"), ("zero_fill", "render_bwd", "bwd_cov2D", "bwd_preprocess")
+        fwd_bytes = sum(alg[k] for k in fwd_keys)
+        bwd_bytes = sum(alg[k] for k in bwd_keys)
+        step_bytes = fwd_bytes + (0 if fwd_only else bwd_bytes)
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(prof["hbm_bytes_per_launch"]) if prof else None,
+                    "traffic_source": prof_note,
+                    "algorithmic_bytes_per_launch": int(alg[dom_key]), "bytes_model": "SURVEY.md section 8(d), verbatim",
+                    "design_bytes_per_launch": int(des[dom_key]), "avg_launch_ms": round(dom_ms, 4),
+                    "whole_step_frac": round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5),
+                    "note": "this kernel is VALU-issue bound, not HBM bound (see \"valu\"); the HBM fraction is reported because the contract asks for it"}
         out = {
             "metric": "fwd+bwd frames/sec at 1920×1080, 1M Gaussians; PSNR vs reference",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -311,22 +359,135 @@ def main():
                        "parallelism": (f"tilerows{world}" if sharded else f"frames{world}") if world > 1 else "single",
                        "scale": args.scale},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "algorithmic_bytes": {"forward": int(fwd_bytes), "backward": int(bwd_bytes)},
-            "roofline": {"bound": "hbm", "kernel": kname,
-                         "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_ms, 4),
-                         "whole_step_frac": round(((fwd_bytes + (0 if fwd_only else bwd_bytes)) / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5)},
+            "algorithmic_bytes": {"forward": int(fwd_bytes), "backward": int(bwd_bytes), "model": "SURVEY.md section 8(d)"},
+            "design_bytes": {"forward": int(sum(des[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "gather", "render_fwd"))),
+                             "backward": int(sum(des[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess")))},
+            "roofline": roofline,
         }
+        if prof and prof.get("SQ_INSTS_VALU") and dom_ms and dom_ms > 0:
+            # VALU view of the dominant kernel, from pass 1 of the same committed profile (SQ counters are sums over the chip):
+            # busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x launch duration x 2.4 GHz nominal);
+            # lane_util = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU / 64; insts_per_pair = wave-instructions x 64 lanes / B
+            simd_cycles = 1024 * (float(prof.get("avg_ms_at_profile", dom_ms)) * 1e-3) * 2.4e9
+            out["valu"] = {"kernel": kname, "busy": round(4.0 * prof["SQ_ACTIVE_INST_VALU"] / simd_cycles, 3),
+                           "wave_insts_per_launch": int(prof["SQ_INSTS_VALU"]),
+                           "insts_per_pair": round(64.0 * prof["SQ_INSTS_VALU"] / B, 1) if B else None,
+                           "lane_util": round(prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"] / 64.0, 3),
+                           "source": prof_note}
         if tile_probe is not None:
             out["tile_shard"] = tile_probe
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, sdict, gy, fwd_only, args.cpu_rows)
+            checker = checker_legs(scene, sdict, gy, fwd_only, args.cpu_rows, state, leaves, raster_factory=lambda e: dgr.GaussianRasterizer(rs._replace(settings=e)),
+                                   es=es, tensors=(means3D, means2D, opac, shs, scales, rots), w_img=w_img)
+            out.update(checker)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 200.0 if mse == 0 else round(10.0 * math.log10(1.0 / mse), 2)
+
+
+def _grad_err(prod, other):
+    """Per gradient tensor: |difference| per Gaussian relative to the tensor's largest entry.  Returns the worst value, the
+    number of Gaussians above 1e-4 in any tensor (a blend on the 1/255 threshold flips with the expf implementation and puts
+    the weight of one pixel into the gradients of the Gaussians blended there) and the worst value among all the others."""
+    per_g = None
+    for k, a in prod.items():
+        b = other.get(k)
+        if a is None or b is None or np.size(b) == 0:
+            continue
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        if k == "dL_dmeans2D":
+            a, b = a[:, :2], b[:, :2]
+        e = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1) / max(float(np.max(np.abs(b))), 1e-30)
+        per_g = e if per_g is None else np.maximum(per_g, e)
+    if per_g is None:
+        return {}
+    over = per_g > 1e-4
+    return {"grad_rel_max": float(per_g.max()), "gaussians_over_1e-4": int(over.sum()),
+            "grad_rel_max_of_the_others": float(per_g[~over].max()) if (~over).any() else 0.0}
+
+
+def _img_err(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+    return {"psnr_db": _psnr(a, b), "max_abs": float(d.max()), "pixels_moved_gt_2e-6": int((d > 2e-6).any(axis=0).sum()), "pixels": int(d[0].size)}
+
+
+def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory, es, tensors, w_img):
+    """The checker / baseline leg (rank 0, N = 1): everything here is test infrastructure from oracle/, used as the thing
+    compared AGAINST and as reported non-target baselines, never as the thing measured.
+      cpu_baseline            the CPU oracle timed on a bounded window of the same frame
+      parity                  product vs that oracle window (image PSNR / max-abs, gradient max error), and -- when
+                              oracle/_ref is present -- product vs THE REFERENCE'S OWN KERNELS on the whole timed frame
+      reference_on_this_gpu   the reference's own kernels (hipify-perl + hipcc build) timed on this GPU, same frame"""
+    means3D, means2D, opac, shs, scales, rots = tensors
+    out = {}
+    base, y0, nrows, ofr, ograds = cpu_baseline(scene, sdict, gy, fwd_only, rows)
+    out["cpu_baseline"] = base
+    names = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")
+    grab = lambda: {n: (None if x.grad is None else x.grad.detach().cpu().numpy()) for n, x in zip(names, (means3D, means2D, opac, scales, rots, shs))}
+    # product on the oracle's window (same private tile-row key the tile-row sharding uses), one untimed step
+    esw = type(es).from_dict(es.to_dict()) if hasattr(type(es), "from_dict") else es
+    base_to_dict = esw.to_dict
+    esw.to_dict = lambda: {**base_to_dict(), "_tile_rows": (y0, y0 + nrows)}
+    rw = raster_factory(esw)
+    for x in leaves:
+        if x is not None:
+            x.grad = None
+    cw, _ = rw(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+    sl = slice(16 * y0, min(16 * (y0 + nrows), scene.H))
+    img_p = cw.detach().cpu().numpy()[:, sl]
+    img_o = ofr.color[:, sl]
+    par = {"against": "CPU oracle (held bit-for-bit to the reference's own IEEE build in all integer / state results: tests/test_reference_golden.py)",
+           "window": f"tile rows {y0}..{y0 + nrows - 1} of {gy} of the timed frame",
+           **_img_err(img_p, img_o)}
+    if not fwd_only:
+        (cw * w_img).sum().backward()
+        par.update(_grad_err(grab(), ograds))
+    ofr.free()
+    out["parity"] = par
+    # the reference itself on this GPU: whole frame, both builds when present
+    try:
+        from oracle import reference as ref
+        full_img = state["color"].detach().cpu().numpy()
+        for x in leaves:
+            if x is not None:
+                x.grad = None
+        if not fwd_only:
+            c_full, _ = raster_factory(es)(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+            (c_full * w_img).sum().backward()
+            full_img = c_full.detach().cpu().numpy()
+            pg = grab()
+        for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
+            if not ref.available(variant):
+                continue
+            rf = ref.forward_scene(scene, sdict, variant=variant)
+            rec = {"build": ref.build_info(variant), "frame": "whole timed frame", "num_rendered_equal": bool(rf.num_rendered == int(out_num_rendered(state, rf))),
+                   **_img_err(full_img, rf.color)}
+            if not fwd_only:
+                rg = rf.backward(scene.dL_dout)
+                rec.update(_grad_err(pg, rg))
+            if variant == "fast":
+                f_ms, b_ms = rf.time_steps(None if fwd_only else scene.dL_dout, warmup=1, steps=3)
+                out["reference_on_this_gpu"] = {
+                    "value": round(1000.0 / (f_ms + b_ms), 3), "unit": "frames/s", "fwd_ms": round(f_ms, 2), "bwd_ms": round(b_ms, 2),
+                    "kind": "the reference's own kernels, hipify-perl + hipcc defaults for gfx950 (oracle/_ref; CUDA-tuned code on wave64, "
+                            "NOT a statement about NVIDIA hardware; nothing is published, so vs_baseline stays null)", "steps": 3}
+            rf.free()
+            par[key] = rec
+    except Exception as ex:  # the headline stands on its own
+        par["vs_reference_error"] = repr(ex)[:300]
+    return out
+
+
+def out_num_rendered(state, rf):
+    fn = state["color"].grad_fn
+    return getattr(fn, "num_rendered", rf.num_rendered) if fn is not None else rf.num_rendered
 
 
 def cpu_baseline(scene, sdict, gy, fwd_only, rows):
@@ -336,14 +497,17 @@ def cpu_baseline(scene, sdict, gy, fwd_only, rows):
     from oracle import oracle as orc
     cores = orc.num_threads()
 
+    keep = {}
+
     def run(r):
         y0 = max(0, (gy - r) // 2)
         t0 = time.perf_counter()
         f = orc.forward_scene(scene, sdict, tile_rows=(y0, y0 + r))
-        if not fwd_only:
-            f.backward(scene.dL_dout)
+        g = None if fwd_only else f.backward(scene.dL_dout)
         dt = time.perf_counter() - t0
-        f.free()
+        if keep.get("f") is not None:
+            keep["f"].free()
+        keep["f"], keep["g"] = f, g     # the last run's outputs double as the parity target (checker_legs)
         return y0, dt
 
     if rows <= 0:
@@ -358,9 +522,10 @@ def cpu_baseline(scene, sdict, gy, fwd_only, rows):
         dt += run(rows)[1]
         reps += 1
     est_frame_s = (dt / reps) * gy / rows
-    return {"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"tile rows {y0}..{y0 + rows - 1} of {gy} of the same frame ({'fwd' if fwd_only else 'fwd+bwd'}), "
-                      f"{reps} repetition(s), {dt:.1f} s measured on {cores} threads, extrapolated x{gy / rows:.2f}"}
+    return ({"value": round(1.0 / est_frame_s, 5), "unit": "frames/s", "cores": cores, "kind": "port",
+             "sample": f"tile rows {y0}..{y0 + rows - 1} of {gy} of the same frame ({'fwd' if fwd_only else 'fwd+bwd'}), "
+                       f"{reps} repetition(s), {dt:.1f} s measured on {cores} threads, extrapolated x{gy / rows:.2f}"},
+            y0, rows, keep["f"], keep["g"])
 
 
 if __name__ == "__main__":

@@ -122,6 +122,16 @@ class Frame:
         buf = (ctypes.c_char * (n * dt.itemsize)).from_address(ptr.value)
         return np.frombuffer(buf, dtype=dt).copy()
 
+    def cull_alpha(self, tile: int, cx: int, cy: int) -> np.ndarray:
+        """opacity*exp(-power) of the 4x4-culling test (double) of every entry of `tile` vs the sub-tile at pixel (cx, cy)."""
+        L = lib()
+        L.orc_cull_alpha.restype = ctypes.c_int
+        L.orc_cull_alpha.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        r = self.array("ranges").reshape(-1, 2)[tile]
+        out = np.zeros(max(1, int(r[1] - r[0])), np.float64)
+        n = L.orc_cull_alpha(self._h, int(tile), int(cx), int(cy), out.ctypes.data_as(ctypes.c_void_p), out.size)
+        return out[:max(n, 0)]
+
     def backward(self, dL_dout: np.ndarray, pixel_colors: Optional[np.ndarray] = None) -> Dict[str, np.ndarray]:
         i = self._in
         P, M = i["P"], i["M"]

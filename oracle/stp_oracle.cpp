@@ -1518,6 +1518,28 @@ void orc_mark_visible(int P, const float* means3D, const float* view, const floa
 void orc_frame_free(OrcFrame* frame) { delete frame; }
 int orc_frame_num_rendered(const OrcFrame* frame) { return frame ? frame->R : -1; }
 
+// Diagnostic for the parity tests: the 4x4-culling alpha (ref: hierarchical_render.cuh:722-743) of every entry of tile
+// `tile` with respect to the sub-tile whose corner pixel is (cx, cy), as opacity * exp(-power) evaluated in DOUBLE on the
+// fp32 `power` the cull test computes -- i.e. how far each entry's decision sits from the 1/255 threshold, independent
+// of which expf implementation rounds it.  Returns the number of entries written (<= cap).
+int orc_cull_alpha(const OrcFrame* f, int tile, int cx, int cy, double* out, int cap)
+{
+    if (!f || !out || tile < 0 || (size_t)(2 * tile + 1) >= f->ranges.size()) return -1;
+    const uint32_t lo = f->ranges[2 * (size_t)tile], hi = f->ranges[2 * (size_t)tile + 1];
+    int n = 0;
+    for (uint32_t i = lo; i < hi && n < cap; i++, n++) {
+        const uint32_t id = f->point_list[i];
+        const float* co = &f->conic_opacity[4 * (size_t)id];
+        const V2 xy = {f->means2D[2 * (size_t)id], f->means2D[2 * (size_t)id + 1]};
+        const V2 rmin = {(float)cx, (float)cy};
+        const V2 rmax = {rmin.x + 3.0f, rmin.y + 3.0f};
+        V2 mp;
+        const float power = max_contrib_power_rect(co, xy, rmin, rmax, 3.0f, 3.0f, mp);
+        out[n] = (double)co[3] * std::exp(-(double)power);
+    }
+    return n;
+}
+
 int64_t orc_frame_array(const OrcFrame* f, const char* name, const void** data)
 {
     if (!f || !name || !data) return -1;

@@ -86,6 +86,9 @@ void orc_frame_free(OrcFrame* frame);
    Returns element count (in units of the scalar type) or -1. */
 int64_t orc_frame_array(const OrcFrame* frame, const char* name, const void** data);
 int orc_frame_num_rendered(const OrcFrame* frame);
+/* Diagnostic: opacity * exp(-power) of the hierarchical 4x4-culling test, in double, for every entry of `tile` against the
+   sub-tile with corner pixel (cx, cy): the distance of each culling decision from the 1/255 threshold. */
+int orc_cull_alpha(const OrcFrame* frame, int tile, int cx, int cy, double* out, int cap);
 
 /* Test-only switches.  "ewa_exact_grad"=1: use the mathematically exact Mip-Splatting scaling
    gradient instead of the reference's (see stp_oracle.cpp backward_preprocess).

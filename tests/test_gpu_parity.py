@@ -52,8 +52,23 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-
     # moves that one pixel by up to 1/255.  Seen: 1 pixel in 83,000 (C4 at 1 % area); allowed: 2 values in 100,000, at least two pixels.
     diff = np.abs(g.color.astype(np.float64) - f.color.astype(np.float64))
     assert diff.max() <= 1.0 / 255.0 + 1e-6
-    flipped = int((diff > img_tol).sum())
-    assert flipped <= max(max_flipped, int(2e-5 * diff.size)), flipped  # (two pixels even in a small image: seen once in 5500 random scenes)
+    moved = diff > img_tol
+    flipped = int(moved.sum())
+    # With hierarchical_4x4_culling ONE threshold decision (opacity * exp(-power) < 1/255 for the sub-tile's best point,
+    # ref: hierarchical_render.cuh:722-743) removes an entry from a whole 4x4 sub-tile.  The device evaluates that exp with
+    # exp_blend (<= 2 ulp), the oracle with libm's expf (<= 1 ulp), so the two sides can disagree only about an entry whose
+    # exact alpha lies within ~3.5 ulp of fp32 (4.2e-7 relative) of 1/255.  A moved sub-tile is accepted ONLY if such an entry
+    # exists in its tile's list (the oracle reports every entry's alpha in double); its pixels then differ by at most that
+    # entry's alpha (<= 1/255, checked above).  Everything else stays under the per-pixel allowance below.
+    unexplained = flipped
+    if flipped and sd["culling_settings"]["hierarchical_4x4_culling"] and sd["sort_settings"]["sort_mode"] == 3:
+        gx = (scene.W + 15) // 16
+        ys, xs = np.nonzero(moved.any(axis=0))
+        for sy, sx in sorted({(int(y) // 4, int(x) // 4) for y, x in zip(ys, xs)}):
+            al = f.cull_alpha((sy // 4) * gx + (sx // 4), 4 * sx, 4 * sy)
+            if al.size and float(np.min(np.abs(al * 255.0 - 1.0))) <= 6e-7:
+                unexplained -= int(moved[:, 4 * sy:4 * sy + 4, 4 * sx:4 * sx + 4].sum())
+    assert unexplained <= max(max_flipped, int(2e-5 * diff.size)), (flipped, unexplained)  # (two pixels even in a small image: seen once in 5500 random scenes)
     assert psnr(g.color, f.color) >= (100.0 if flipped == 0 else 75.0)  # (one flipped pixel of a 1600-pixel image: 80 dB)
     # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
     # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise
