@@ -12,9 +12,11 @@
 // single timed caller (bench.py, the viewer's timings text).
 #include "stp_internal.h"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 
 namespace stp {
@@ -222,6 +224,41 @@ using namespace stp;
         }                                                                        \
     } while (0)
 
+// ---- num_rendered mailbox: host-mapped pinned words + an event, a small ring per device (concurrent forwards on one
+// ---- device -- several streams or threads -- each get their own slot)
+namespace {
+struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev = nullptr; int device = 0; };
+constexpr int MAX_DEVICES = 32, MAILBOX_RING = 8;
+struct MailboxRing { Mailbox slot[MAILBOX_RING]; std::atomic<unsigned> next{0}; bool ready = false; };
+MailboxRing g_mailboxes[MAX_DEVICES];
+std::mutex g_mailbox_mutex;
+std::atomic<uint32_t> g_last_R[MAX_DEVICES]; // tile-list entries of the previous forward on each device (binning-size guess)
+
+int acquire_mailbox(Mailbox* out)
+{
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= MAX_DEVICES) return fail(STP_ERR_HIP, "hipGetDevice failed");
+    MailboxRing& ring = g_mailboxes[device];
+    if (!ring.ready) {
+        std::lock_guard<std::mutex> lock(g_mailbox_mutex);
+        if (!ring.ready) {
+            for (int i = 0; i < MAILBOX_RING; i++) {
+                void* h = nullptr; void* d = nullptr;
+                if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess ||
+                    hipEventCreateWithFlags(&ring.slot[i].ev, hipEventDisableTiming) != hipSuccess)
+                    return fail(STP_ERR_HIP, "cannot create the num_rendered mailbox");
+                ring.slot[i].host = static_cast<volatile uint32_t*>(h);
+                ring.slot[i].dev = static_cast<uint32_t*>(d);
+                ring.slot[i].device = device;
+            }
+            ring.ready = true;
+        }
+    }
+    *out = ring.slot[ring.next.fetch_add(1u) % MAILBOX_RING];
+    return 0;
+}
+} // namespace
+
 extern "C" {
 
 int stp_abi_version(void) { return STP_ABI_VERSION; }
@@ -386,19 +423,42 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_DEBUG_SYNC("scan");
     if (atomic_bin) STP_TRY(launch_tile_scan(f, img, st), "tile scan"); // counters -> ranges + cursors (no host value needed)
 
-    // the one mandatory host synchronisation: num_rendered sizes the binning buffers (reference :317)
-    uint32_t host_status[2] = {0, 0};
-    STP_TRY(hipMemcpyAsync(&host_status[0], g.point_offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read num_rendered");
-    STP_TRY(hipMemcpyAsync(&host_status[1], g.status + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, st), "read status");
-    STP_TRY(hipStreamSynchronize(st), "synchronize (num_rendered)");
+    // The one mandatory host hand-over: num_rendered sizes the binning buffers (reference :317, a blocking 4-byte copy into
+    // pageable memory).  Here a one-thread kernel drops the two words into host-mapped pinned memory and an event marks
+    // the spot; the SH -> RGB kernel -- which nothing before the render stage depends on -- is enqueued BEHIND it, so
+    // the GPU keeps working while the host wakes up, sizes the buffer and launches duplicate / sort.
+    Mailbox mb;
+    if (int rc = acquire_mailbox(&mb)) return rc;
+    STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, st), "mailbox launch");
+    STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
+    STP_TRY(launch_sh_color(f, g, radii, st), "SH colour launch");
+    // the binning buffer is requested BEFORE the wait, sized by the previous frame's count on this device (+12.5 %): in
+    // the steady state of training or serving no allocator callback runs between the kernels.  The exact-size request of
+    // the reference follows only when the guess was too small (STP_BINNING=exact: always).
+    static const char* const bin_env = std::getenv("STP_BINNING");
+    static const bool speculative = !(bin_env && std::strcmp(bin_env, "exact") == 0);
+    size_t bin_have = 0;
+    char* bin_ptr = nullptr;
+    const uint32_t guess = speculative ? g_last_R[mb.device].load(std::memory_order_relaxed) : 0u;
+    if (guess > 0) {
+        carve_binning(nullptr, (size_t)guess + guess / 8, &bin_have);
+        bin_ptr = (char*)binning_alloc(binning_user, bin_have);
+        if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
+    }
+    STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");
+    const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
     if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     const int R = (int)host_status[0];
+    g_last_R[mb.device].store((uint32_t)R, std::memory_order_relaxed);
+    STP_DEBUG_SYNC("SH colour");
     g_timer.mark(1, st);
 
     size_t bin_bytes = 0;
     carve_binning(nullptr, (size_t)R, &bin_bytes);
-    char* bin_ptr = (char*)binning_alloc(binning_user, bin_bytes);
-    if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
+    if (bin_bytes > bin_have) {
+        bin_ptr = (char*)binning_alloc(binning_user, bin_bytes);
+        if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
+    }
     BinningState b = carve_binning(bin_ptr, (size_t)R, nullptr);
 
     STP_TRY(launch_duplicate(f, g, radii, b, atomic_bin ? img.tile_cursor : nullptr, st), "duplicate launch");

@@ -39,14 +39,14 @@ struct PreArgs {
 };
 
 // SH -> RGB, reference forward_common.h:20-70 (same association of the sums)
-__device__ __forceinline__ void sh_to_rgb(int idx, int deg, int M, float3 mean, float3 cam, const float* __restrict__ shs,
+// `sh`: the Gaussian's own 3M coefficients (a row of the workgroup's LDS staging area in sh_color_kernel)
+__device__ __forceinline__ void sh_to_rgb(int idx, int deg, float3 mean, float3 cam, const float* __restrict__ sh,
                                           uint8_t* __restrict__ clamped, float* __restrict__ rgb)
 {
 #pragma clang fp contract(off)
     float dx = mean.x - cam.x, dy = mean.y - cam.y, dz = mean.z - cam.z;
     const float len = sqrtf(dx * dx + dy * dy + dz * dz);
     const float x = dx / len, y = dy / len, z = dz / len;
-    const float* sh = shs + (size_t)idx * M * 3;
     float res[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) res[ch] = kSH_C0 * sh[ch];
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     }
 
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
-    if (a.colors_precomp == nullptr) sh_to_rgb(idx, a.D, a.M, mean, cam, a.shs, a.g.clamped, a.g.rgb);
+    // (SH -> RGB is sh_color_kernel's: it runs BEHIND the num_rendered read-back, see stp_forward)
 
     if (a.g.cov3D_inv != nullptr) { // reference forward.cu:208-220, stopthepop_common.cuh:13-41
         const float3 sc = make_float3(a.scales[3 * (size_t)idx], a.scales[3 * (size_t)idx + 1], a.scales[3 * (size_t)idx + 2]);
@@ -240,6 +240,57 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
         gp[1] = make_float4(s1.y, s1.z, s2.x, s2.y);
         gp[2] = make_float4(s2.z, mean2D.x, mean2D.y, 0.0f);
         gp[3] = co;
+    }
+}
+
+// SH -> RGB for the visible Gaussians (reference computeColorFromSH, forward_common.h:20-70, called from preprocessCUDA
+// forward.cu:197-205).  A kernel of its own for two reasons: (1) nothing before the render stage needs the colours, so
+// the host enqueues it AFTER the num_rendered mailbox write and it keeps the GPU busy while the host wakes up, sizes
+// the binning buffer and launches the next stages (the read-back bubble of the reference's flow, rasterizer_impl.cu:317,
+// disappears behind it); (2) a thread-per-Gaussian read of 3M consecutive floats is a 192-byte-stride gather: the
+// workgroup moves its 256 rows through LDS with coalesced 16-byte loads instead (rows padded to 3M+1 words), exactly as
+// preprocess_backward_kernel does.
+struct ShArgs {
+    int P, D, M;
+    const float* means3D;
+    const float* shs;
+    const float* cam;
+    const int* radii;
+    uint8_t* clamped;
+    float* rgb;
+};
+
+__global__ void __launch_bounds__(256) sh_color_kernel(const ShArgs a)
+{
+    extern __shared__ float s_rows[]; // [256][3M + 1]
+    const int tid = (int)threadIdx.x;
+    const int base = (int)blockIdx.x * 256;
+    const int idx = base + tid;
+    const int rows = min(256, a.P - base);
+    const int row_len = 3 * a.M, row_stride = row_len + 1;
+    // (no early exit on "nobody visible": it would put the radii load in front of the coefficient loads -- two dependent
+    // memory latencies per workgroup instead of one; the loads below do not wait for this one)
+    const int my_radius = idx < a.P ? a.radii[idx] : 0;
+    const float* __restrict__ src = a.shs + (size_t)base * row_len;
+    const int total = rows * row_len;
+    if ((row_len & 3) == 0) {
+        for (int f = 4 * tid; f < total; f += 4 * 256) {
+            const float4 v = *reinterpret_cast<const float4*>(src + f);
+            const int r = f / row_len, j = f - r * row_len;
+            float* d = s_rows + r * row_stride + j;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int f = tid; f < total; f += 256) {
+            const int r = f / row_len, j = f - r * row_len;
+            s_rows[r * row_stride + j] = src[f];
+        }
+    }
+    __syncthreads();
+    if (my_radius > 0) {
+        const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
+        const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
+        sh_to_rgb(idx, a.D, mean, cam, s_rows + tid * row_stride, a.clamped, a.rgb);
     }
 }
 
@@ -376,6 +427,34 @@ hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const 
     a.tile_cursor = tile_cursor;
     a.keys = tile_cursor ? b.keys : b.keys_unsorted; a.values = tile_cursor ? b.point_list : b.point_list_unsorted;
     hipLaunchKernelGGL(duplicate_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st)
+{
+    if (f.colors_precomp != nullptr || f.shs == nullptr || f.M <= 0) return hipSuccess; // reference forward.cu:200: precomputed colours win
+    ShArgs a;
+    a.P = f.P; a.D = f.D; a.M = f.M; a.means3D = f.means3D; a.shs = f.shs; a.cam = f.cam_pos; a.radii = radii; a.clamped = g.clamped; a.rgb = g.rgb;
+    const size_t lds = (size_t)256 * (3 * a.M + 1) * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sh_color_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sh_color_kernel, dim3((f.P + 255) / 256), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+// num_rendered (the scan's last element) and the status word into host-mapped memory: the forward's one host hand-over
+__global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const uint32_t* __restrict__ status, volatile uint32_t* mailbox)
+{
+    mailbox[0] = *last_offset;
+    mailbox[1] = *status;
+    __threadfence_system();
+}
+
+hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, hipStream_t st)
+{
+    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, last_offset, status, mailbox_dev);
     return hipGetLastError();
 }
 

@@ -35,6 +35,13 @@ namespace {
 #define STP_REPLAY_PAIRMERGE 3 // merge levels: 1 = inside 2x2 quads (lane^1, lane^2), 2 = + mirror in the 8-lane half, 3 = + mirror in the 16-lane row
                                // (C2-full: 1.38 ms without, 0.99 / 0.95 / 0.94 ms with 1 / 2 / 3)
 #endif
+#ifndef STP_REPLAY_F64
+#define STP_REPLAY_F64 0 // 1: on-chip sums as doubles through ds_add_f64 instead of 64-bit fixed point (one conversion per term instead of
+                         // four instructions, no range check).  MEASURED SLOWER on MI355X: ds_add_f64 costs 9 cycles per wave
+                         // instruction on distinct addresses like ds_add_u64, but 42 / 181 cycles when 4 / 16 lanes share an address
+                         // (u64: 27 / 119; tools/lds_atomic_bench.hip), and this kernel lives on shared addresses: C2-full replay
+                         // 0.98 -> 1.36 ms.  Kept as a switch for the record.
+#endif
 #ifndef STP_REPLAY_OCC
 #define STP_REPLAY_OCC 4
 #endif
@@ -53,6 +60,7 @@ __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
 __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(const RenderArgs a)
 {
     __shared__ unsigned long long s_acc[9 * WINDOW]; // [term][position - window start]
+    double* const s_accd = reinterpret_cast<double*>(s_acc); // STP_REPLAY_F64: the same sums as doubles (ds_add_f64)
     __shared__ float s_md[4];
 
     const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
@@ -156,6 +164,12 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         }
 #endif
         if (ok) {
+#if STP_REPLAY_F64
+            if (cur_pos >= lo) { // nine ds_add_f64, nothing else (one v_cvt per term; no range check, no fixed-point scale)
+#pragma unroll
+                for (int kk = 0; kk < 9; kk++) atomicAdd(&s_accd[kk * WINDOW + (cur_pos - lo)], (double)g[kk]);
+            } else {
+#else
             float gmax = fabsf(g[0]);
 #pragma unroll
             for (int kk = 1; kk < 9; kk++) gmax = fmaxf(gmax, fabsf(g[kk]));
@@ -168,6 +182,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                     atomicAdd(&s_acc[kk * WINDOW + (cur_pos - lo)], (unsigned long long)qv);
                 }
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
+#endif
 #pragma unroll
                 for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
             }
@@ -180,11 +195,19 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         const int term = lane & 15, cnt = min(WINDOW, list_len - lo);
         for (int p = (int)(threadIdx.x >> 4); p < cnt; p += 16) {
             if (term < 9) {
+#if STP_REPLAY_F64
+                const double v = s_accd[term * WINDOW + p];
+                if (v != 0.0) {
+                    s_accd[term * WINDOW + p] = 0.0;
+                    atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)v);
+                }
+#else
                 const long long v = (long long)s_acc[term * WINDOW + p];
                 if (v != 0) {
                     s_acc[term * WINDOW + p] = 0ull;
                     atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)((double)v * fx_inv));
                 }
+#endif
             }
         }
     };

@@ -51,7 +51,12 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
     __shared__ uint64_t s_key[CAP]; // (depth bits << 32) | Gaussian id
     __shared__ int s_cnt[3 * 256];  // long segments only: digits of a chunk, histogram, bases
     const int tid = (int)threadIdx.x;
-    const uint2 range = a.ranges[blockIdx.x];
+    // XCD-aware tile order (same map as the render kernels): workgroup ids are dealt round-robin to the 8 XCDs, so each XCD gets
+    // a contiguous run of tiles and the 64-byte lines of the Gaussians that neighbouring tiles share hit in that XCD's L2
+    const int n_wg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int xq = n_wg >> 3, xr = n_wg & 7, xcd = wg & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
+    const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n <= MIN_N || (CAP == TS_SMALL && n > TS_SMALL)) return; // empty, or the other instantiation's tile
     uint64_t* const keys = a.keys + range.x;

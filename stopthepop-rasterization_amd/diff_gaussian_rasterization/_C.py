@@ -146,30 +146,61 @@ def _stream_ptr(device) -> ctypes.c_void_p:
 # therefore kept on a small free list of our own: handed out by the forward, handed back by the backward.
 _BIG_BYTES = 256 << 20
 _BIG_STEP = 64 << 20
-_BIG_KEEP = 4                # free buffers kept per device
-_big_free = {}               # device index -> [tensor, ...]
+_BIG_KEEP = 4                # free buffers kept per device (see also set_scratch_pool_limit)
+_big_max_bytes = None        # optional cap on the bytes the free list may hold per device
+_big_free = {}               # device index -> [(tensor, event recorded on the releasing stream), ...]
 _big_generation = {}         # data_ptr -> how many times the buffer at this address was handed out
 
 
+def clear_scratch_pool(device=None) -> int:
+    """Drops the pooled scratch buffers (tile lists / blend logs waiting for reuse) of `device` (all devices when None) so
+    that torch.cuda.empty_cache() can hand their memory back; returns the number of bytes released.  Buffers that a live
+    autograd graph still holds are not affected."""
+    freed = 0
+    for d in list(_big_free) if device is None else [torch.device(device).index if not isinstance(device, int) else device]:
+        for t, _ in _big_free.pop(d, []):
+            freed += t.numel()
+    return freed
+
+
+def set_scratch_pool_limit(max_buffers: int = 4, max_bytes=None) -> None:
+    """Bounds the free list: at most `max_buffers` buffers and (optionally) `max_bytes` bytes per device stay pooled."""
+    global _BIG_KEEP, _big_max_bytes
+    _BIG_KEEP, _big_max_bytes = int(max_buffers), (None if max_bytes is None else int(max_bytes))
+
+
 class _Resizer:
-    """The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request."""
+    """The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request.  The library may
+    call it twice per forward (a size guess before the num_rendered hand-over, the exact size afterwards if the guess
+    was short): a request the current buffer already covers returns the same pointer."""
 
     def __init__(self, device, pooled=False):
         self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
         self.pooled = pooled
+        self.from_pool = False
         self.cb = _ALLOC_FN(self._alloc)
 
     def _alloc(self, _user, nbytes):
         try:
             nbytes = int(nbytes)
+            if nbytes <= self.tensor.numel() and nbytes > 0:
+                return self.tensor.data_ptr()
             if self.pooled and nbytes >= _BIG_BYTES:
+                if self.from_pool:       # the guess was too small: the buffer goes back, a larger one comes
+                    _put_back(self.tensor)
                 # capacity in steps of 64 MiB, so that a buffer whose size follows the number of tile-list entries
                 # (it changes a little from view to view) finds its predecessor on the free list
                 cap = (nbytes + _BIG_STEP - 1) // _BIG_STEP * _BIG_STEP
                 free = _big_free.setdefault(self.tensor.device.index, [])
-                fits = [i for i, t in enumerate(free) if nbytes <= t.numel() <= cap + cap // 4]
-                hit = min(fits, key=lambda i: free[i].numel()) if fits else None
-                self.tensor = free.pop(hit) if hit is not None else torch.empty(cap, dtype=torch.uint8, device=self.tensor.device)
+                fits = [i for i, (t, _) in enumerate(free) if nbytes <= t.numel() <= cap + cap // 4]
+                hit = min(fits, key=lambda i: free[i][0].numel()) if fits else None
+                if hit is not None:
+                    self.tensor, ev = free.pop(hit)
+                    if ev is not None:   # the releasing stream's kernels may still be reading it: order this stream behind them
+                        torch.cuda.current_stream(self.tensor.device).wait_event(ev)
+                else:
+                    self.tensor = torch.empty(cap, dtype=torch.uint8, device=self.tensor.device)
+                self.from_pool = True
                 ptr = self.tensor.data_ptr()
                 _big_generation[ptr] = _big_generation.get(ptr, 0) + 1
                 return ptr
@@ -192,16 +223,22 @@ def check_scratch(buf: torch.Tensor, generation: int) -> None:
                            "pass; run the forward again before this backward")
 
 
+def _put_back(buf: torch.Tensor) -> None:
+    free = _big_free.setdefault(buf.device.index, [])
+    if any(t.data_ptr() == buf.data_ptr() for t, _ in free):
+        return
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(buf.device))
+    free.append((buf, ev))
+    while len(free) > _BIG_KEEP or (_big_max_bytes is not None and len(free) > 1 and sum(t.numel() for t, _ in free) > _big_max_bytes):
+        free.pop(0)
+
+
 def release_scratch(buf: torch.Tensor) -> None:
-    """Hand a pooled buffer back after the backward that consumed it."""
+    """Hand a pooled buffer back after the backward that consumed it (reuse is ordered behind the releasing stream)."""
     if buf.numel() < _BIG_BYTES or not buf.is_cuda:
         return
-    free = _big_free.setdefault(buf.device.index, [])
-    if any(t.data_ptr() == buf.data_ptr() for t in free):
-        return
-    free.append(buf)
-    while len(free) > _BIG_KEEP:
-        free.pop(0)
+    _put_back(buf)
 
 
 def _require_gpu(means3D: torch.Tensor):

@@ -9,8 +9,9 @@ __global__ void __launch_bounds__(256) k(int iters, float* out)
     __shared__ float sf[4][9 * 128];
     __shared__ unsigned int su[4][9 * 128];
     __shared__ unsigned long long sl[4][9 * 128];
+    __shared__ double sd[4][9 * 128];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int i = lane; i < 9 * 128; i += 64) { sf[w][i] = 0; su[w][i] = 0; sl[w][i] = 0; }
+    for (int i = lane; i < 9 * 128; i += 64) { sf[w][i] = 0; su[w][i] = 0; sl[w][i] = 0; sd[w][i] = 0; }
     __syncthreads();
     unsigned int rng = blockIdx.x * 977 + w * 131 + 7;
     float acc = 0;
@@ -25,10 +26,12 @@ __global__ void __launch_bounds__(256) k(int iters, float* out)
             if (MODE == 2) atomicAdd(&sl[w][kk * 128 + slot], (unsigned long long)(long long)(v * 1048576.0f));
             if (MODE == 3) { float t = sf[w][kk * 128 + slot]; sf[w][kk * 128 + slot] = t + v; }
             if (MODE == 4) acc += __shfl_xor(v, 1) + v;
+            if (MODE == 5) atomicAdd(&sd[w][kk * 128 + slot], (double)v);
+            if (MODE == 6) { const double tq = fma((double)v, 1048576.0, 6755399441055744.0); atomicAdd(&sl[w][kk * 128 + slot], (unsigned long long)(__double_as_longlong(tq) - 0x4338000000000000ll)); }
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) out[blockIdx.x] = sf[0][3] + (float)su[0][3] + (float)sl[0][3] + acc;
+    if (threadIdx.x == 0) out[blockIdx.x] = sf[0][3] + (float)su[0][3] + (float)sl[0][3] + (float)sd[0][3] + acc;
 }
 template <int MODE, int GROUP> void run(const char* name)
 {
@@ -52,5 +55,7 @@ int main()
     run<2, 1>("ds_add_u64"); run<2, 4>("ds_add_u64"); run<2, 16>("ds_add_u64");
     run<3, 1>("plain read+write"); run<3, 4>("plain read+write");
     run<4, 1>("valu baseline");
+    run<5, 1>("ds_add_f64"); run<5, 4>("ds_add_f64"); run<5, 16>("ds_add_f64");
+    run<6, 1>("fixed-point u64 (fma trick)"); run<6, 4>("fixed-point u64 (fma trick)");
     return 0;
 }
