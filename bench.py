@@ -10,11 +10,12 @@ rect/tight/tile-based/4x4 culling + load balancing, `--variant min` = plain Z or
 resident in HBM, through the public drop-in API (GaussianRasterizer -> autograd -> _C -> C ABI).
 Rank 0 prints ONE JSON line (contract in the task statement / DESIGN.md section "Measurement").
 
-N > 1: the unit of the metric is a frame, and frames are independent, so the headline shards FRAMES over the ranks
-(`--shard frames`, the default): every rank renders its own frame, no data-path collective, weak scaling.  The same
-run then also times the north star's optional mode -- ONE frame partitioned by screen-tile row, image strips gathered
-to rank 0 over RCCL, per-Gaussian gradient records all-reduced (strong scaling) -- and reports it in the `tile_shard`
-object of the JSON line.  `--shard tilerows` makes that mode the headline instead.
+N > 1: the unit of the metric is a frame, and frames are independent, so the C2 headline shards FRAMES over the ranks
+(`--shard frames`): every rank renders its own frame, no data-path collective, weak scaling.  The same run then also
+times the north star's tile-row mode -- ONE frame partitioned by screen-tile row, image strips sent to rank 0 over RCCL,
+per-Gaussian gradient records all-reduced (strong scaling) -- and reports it in the `tile_shard` object of the JSON
+line (`--no-tile-shard-probe` leaves it out).  `--shard tilerows` makes that mode the headline; it is the default for
+`--workload C4`, BASELINE's 4K serving configuration.
 
 The `cpu_baseline` leg (rank 0, N == 1 only) times the CPU oracle on a bounded sample of the same frame:
 it is a reported, non-target baseline.
@@ -135,11 +136,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5"])
     ap.add_argument("--variant", default="full", choices=["full", "min"])
-    ap.add_argument("--shard", default="frames", choices=["tilerows", "frames"])
-    ap.add_argument("--tile-shard-probe", action="store_true",
-                    help="N > 1 with --shard frames: additionally time one frame sharded by tile row over all ranks (extra \"tile_shard\" "
-                         "object; off by default so that the headline run contains no collective beyond its barriers)")
-    ap.add_argument("--no-tile-shard-probe", action="store_true", help="(accepted, no effect: the probe is opt-in)")
+    ap.add_argument("--shard", default=None, choices=["tilerows", "frames"],
+                    help="N > 1: what the ranks share.  Default: tilerows for C4 (BASELINE's 4K serving configuration IS the tile-row shard "
+                         "with an RCCL gather), frames otherwise (the metric's unit is a frame and frames are independent)")
+    ap.add_argument("--tile-shard-probe", action="store_true", help="(accepted, no effect: the probe runs by default when N > 1)")
+    ap.add_argument("--no-tile-shard-probe", action="store_true",
+                    help="N > 1 with --shard frames: do NOT additionally time one frame sharded by tile row over all ranks (the \"tile_shard\" "
+                         "object of the JSON line; a fault in it degrades to an error field, the headline stands on its own)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalidates the headline number)")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps (device clock ramp)")
@@ -179,6 +182,8 @@ def main():
     from diff_gaussian_rasterization import _C, scenes, tile_shard
 
     fwd_only = args.fwd_only or args.workload == "C4"
+    if args.shard is None:
+        args.shard = "tilerows" if args.workload == "C4" else "frames"
     scene = scenes.config(args.workload, scale=args.scale)
     es = settings_for(args.variant, args.workload)
     sdict = es.to_dict()
@@ -259,7 +264,7 @@ def main():
 
     # auxiliary measurement (N > 1, or --force-shard handled above): one frame sharded by tile row over all ranks
     tile_probe = None
-    if world > 1 and not sharded and args.tile_shard_probe:
+    if world > 1 and not sharded and not args.no_tile_shard_probe:
         try:
             r2 = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
 
@@ -285,7 +290,7 @@ def main():
             dt2 = float(tt2.item())
             tile_probe = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
                           "scaling": "strong", "parallelism": f"tilerows{world}",
-                          "exchange": "gather of image strips to rank 0 + all-reduce of 36 B per Gaussian (RCCL)"}
+                          "exchange": "three channel segments per peer sent straight into rank 0's frame (grouped RCCL send/recv) + all-reduce of 36 B per Gaussian"}
         except Exception as ex:  # the headline above stands on its own
             tile_probe = {"error": repr(ex)[:300]}
 

@@ -5,9 +5,9 @@ After binning, screen tiles are independent, so rank g of G owns the tile rows
 per-Gaussian preprocess on all of it (cheap, HBM-streaming), but bins, sorts and blends only the tiles
 of its rows (StpSettings.tile_y0/tile_y1).  Exchange steps:
 
-  forward  : the image strips are gathered to rank 0 (`dist.gather` = grouped point-to-point
-             send/recv in RCCL: every peer->root transfer rides its own xGMI link; a ring would be
-             bound by one link) -- or all-gathered when every rank needs the frame;
+  forward  : the image strips go to rank 0 as grouped point-to-point sends (three contiguous channel segments per
+             peer, received straight into the rows of the root's own output tensor: every peer->root transfer rides
+             its own xGMI link; a ring would be bound by one link) -- or are all-gathered when every rank needs the frame;
   backward : the render half runs on the rank's rows only and yields PARTIAL per-Gaussian sums
              (one 64-byte gradient record per Gaussian, see include/stp_raster.h); they are linear
              inputs of the per-Gaussian backward, so ONE all-reduce(sum) of the (P,16) record buffer precedes
@@ -62,19 +62,79 @@ def assemble(strips: List[torch.Tensor], parts: List[Tuple[int, int]], height: i
     return out
 
 
+def balanced_partition(row_cost, world: int) -> List[Tuple[int, int]]:
+    """Contiguous tile-row blocks of (nearly) equal COST instead of equal height: row_cost[y] = work of tile row y (the
+    number of tile-list entries of its tiles is a good proxy for the blend time).  Cut k goes where the running sum
+    first reaches k/world of the total; every rank gets at least zero rows, the blocks tile [0, n_rows) in order.
+    SURVEY.md 8(e): "optional re-partition by per-row duplicate histogram"."""
+    cost = [max(0.0, float(c)) for c in row_cost]
+    n = len(cost)
+    total = sum(cost)
+    if total <= 0.0 or world <= 1:
+        return row_partition(n, world)
+    cuts, run, y = [0], 0.0, 0
+    for k in range(1, world):
+        target = total * k / world
+        while y < n and run + 0.5 * cost[y] < target:   # a row goes to the side its midpoint falls on
+            run += cost[y]
+            y += 1
+        cuts.append(y)
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def _host_staged(dist) -> bool:
+    """gloo moves host memory only: device tensors are staged through the host (CPU tests, and the 2-process test that runs
+    the HIP path with both ranks on ONE GPU).  RCCL (backend "nccl") takes device pointers and uses xGMI."""
+    try:
+        return dist.get_backend() == "gloo"
+    except Exception:
+        return False
+
+
 def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, dst: int = 0, to_all: bool = False):
-    """Exchange step of the forward.  Returns the assembled (3,H,W) frame on `dst` (every rank if to_all),
-    None elsewhere."""
+    """Exchange step of the forward.  `local_image` is this rank's (3,H,W) output with its own pixel rows rendered.
+    Root gather (default): in CHW layout a rank's strip is THREE contiguous segments (one per channel); every peer
+    sends its three segments and the root receives them straight into the rows of ITS OWN output tensor -- one grouped
+    batch of point-to-point operations (ncclGroupStart/End under batch_isend_irecv), every peer -> root transfer on its
+    own xGMI link, no padding, no staging copy, no assembly pass.  Returns the assembled frame (the
+    root's local_image itself, completed in place) on `dst`, None elsewhere.
+    to_all: every rank needs the frame -> all-gather of equal-size padded strips + one assembly copy."""
     H = local_image.shape[1]
-    rows_max = max(1, max(b - a for a, b in parts))
-    strip = pack_strip(local_image, parts[rank], rows_max)
     if to_all:
-        bufs = [torch.empty_like(strip) for _ in range(world)]
-        dist.all_gather(bufs, strip)
-        return assemble(bufs, parts, H)
-    bufs = [torch.empty_like(strip) for _ in range(world)] if rank == dst else None
-    dist.gather(strip, bufs, dst=dst)
-    return assemble(bufs, parts, H) if rank == dst else None
+        rows_max = max(1, max(b - a for a, b in parts))
+        strip = pack_strip(local_image, parts[rank], rows_max)
+        staged = _host_staged(dist) and strip.is_cuda
+        s_ = strip.cpu() if staged else strip
+        bufs = [torch.empty_like(s_) for _ in range(world)]
+        dist.all_gather(bufs, s_)
+        out = assemble(bufs, parts, H)
+        return out.to(local_image.device) if staged else out
+    staged = _host_staged(dist) and local_image.is_cuda
+    ops, landing = [], []
+    if rank == dst:
+        for r in range(world):
+            py0, py1 = strip_pixels(parts[r], H)
+            if r == dst or py1 <= py0:
+                continue
+            for c in range(local_image.shape[0]):
+                seg = local_image[c, py0:py1, :]                      # contiguous: rows of one channel
+                buf = torch.empty(seg.shape, dtype=seg.dtype) if staged else seg
+                landing.append((seg, buf))
+                ops.append(dist.P2POp(dist.irecv, buf, r))
+    else:
+        py0, py1 = strip_pixels(parts[rank], H)
+        if py1 > py0:
+            for c in range(local_image.shape[0]):
+                seg = local_image[c, py0:py1, :]
+                ops.append(dist.P2POp(dist.isend, seg.cpu() if staged else seg, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if staged:
+        for seg, buf in landing:
+            seg.copy_(buf)
+    return local_image if rank == dst else None
 
 
 RECORD_USED = 9  # floats of a gradient record that carry data (include/stp_raster.h, stp_backward)
@@ -108,10 +168,17 @@ class _ShardedRasterize(torch.autograd.Function):
     """rasterize_gaussians for one rank's tile rows + the two exchange steps."""
 
     @staticmethod
-    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard):
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, shard, shard_state=None):
         dist, rank, world, parts, to_all = shard
+        if rs.render_depth:
+            # the depth visualisation normalises by the FRAME's depth extrema (reference rasterizer_impl.cu:54-109); a rank only
+            # sees its rows, so the strips would be normalised differently and the assembled picture would have seams
+            raise RuntimeError("render_depth is not available with tile-row sharding (the depth colormap is normalised by the "
+                               "whole frame's extrema); render it on one GPU")
         sdict = dict(rs.settings.to_dict())
-        sdict["_tile_rows"] = parts[rank]
+        y0, y1 = parts[rank]
+        n_rows = tile_rows(rs.image_height)
+        sdict["_tile_rows"] = (y0, y1) if y1 > y0 else (n_rows, n_rows)   # (an empty block; (0, 0) would mean "all rows" to the library)
         if any(ctx.needs_input_grad) and not rs.render_depth:
             sdict["_record_blend_log"] = True
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -123,6 +190,8 @@ class _ShardedRasterize(torch.autograd.Function):
         ctx.bin_generation = _C.scratch_generation(binningBuffer)
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
+        if shard_state is not None:   # per-row work of this frame (own rows) for the next frame's partition
+            shard_state["pending"] = (imgBuffer, rs.image_width, rs.image_height)
         full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
         ctx.mark_non_differentiable(radii)
         # every rank returns a (3,H,W) tensor: the assembled frame where it is available, else the local strip image
@@ -143,14 +212,19 @@ class _ShardedRasterize(torch.autograd.Function):
         # sum over ranks.  Only 9 of a record's 16 floats carry data (the padding buys single-request atomics on
         # chip, it should not cross xGMI): 36 instead of 64 bytes per Gaussian on the wire.
         used = records[:, :RECORD_USED].contiguous()
-        dist.all_reduce(used)
+        if _host_staged(dist) and used.is_cuda:
+            host = used.cpu()
+            dist.all_reduce(host)
+            used = host.to(records.device)
+        else:
+            dist.all_reduce(used)
         records[:, :RECORD_USED] = used
         out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
         _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
-                grad_cov3Ds_precomp, None, None)
+                grad_cov3Ds_precomp, None, None, None)
 
 
 class TileRowShardedRasterizer(torch.nn.Module):
@@ -160,10 +234,33 @@ class TileRowShardedRasterizer(torch.nn.Module):
     The loss must be evaluated so that each rank back-propagates the gradient of ITS rows (e.g. a per-pixel
     loss evaluated redundantly, or dL/dimage scattered from rank 0)."""
 
-    def __init__(self, raster_settings, dist, rank: int, world: int, to_all: bool = False):
+    def __init__(self, raster_settings, dist, rank: int, world: int, to_all: bool = False, rebalance: bool = False):
+        """rebalance: re-partition the tile rows before every frame by the PREVIOUS frame's per-row tile-list lengths (one
+        all-reduce of n_rows integers per frame) so that ranks get equal work, not equal height -- for scenes whose
+        content is not uniform over the image.  Off by default: the partition is then the fixed ceil(Ty/G) blocks."""
         super().__init__()
         self.raster_settings = raster_settings
-        self.parts = row_partition(tile_rows(raster_settings.image_height), world)
+        self.n_rows = tile_rows(raster_settings.image_height)
+        self.parts = row_partition(self.n_rows, world)
+        self._comm = (dist, rank, world, to_all)
+        self.shard = (dist, rank, world, self.parts, to_all)
+        self.state = {"pending": None} if rebalance else None
+
+    def _repartition(self):
+        """per-row entry counts of the last frame (own rows) -> summed over ranks -> balanced_partition"""
+        dist, rank, world, to_all = self._comm
+        img, W, H = self.state["pending"]
+        self.state["pending"] = None
+        gx = (W + 15) // 16
+        r = _C.image_array(img, W, H, "ranges").reshape(-1, 2)[: gx * self.n_rows].to(torch.int64)
+        cost = (r[:, 1] - r[:, 0]).reshape(self.n_rows, gx).sum(dim=1).to(torch.float32)
+        if _host_staged(dist) and cost.is_cuda:
+            host = cost.cpu()
+            dist.all_reduce(host)
+            cost = host
+        else:
+            dist.all_reduce(cost)
+        self.parts = balanced_partition(cost.tolist(), world)
         self.shard = (dist, rank, world, self.parts, to_all)
 
     def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
@@ -174,5 +271,7 @@ class TileRowShardedRasterizer(torch.nn.Module):
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
         empty = lambda t: torch.Tensor([]) if t is None else t
+        if self.state is not None and self.state["pending"] is not None:
+            self._repartition()
         return _ShardedRasterize.apply(means3D, means2D, empty(shs), empty(colors_precomp), opacities, empty(scales),
-                                       empty(rotations), empty(cov3D_precomp), self.raster_settings, self.shard)
+                                       empty(rotations), empty(cov3D_precomp), self.raster_settings, self.shard, self.state)

@@ -170,6 +170,21 @@ def _free_port():
     return p
 
 
+def test_balanced_partition_by_row_cost():
+    """Contiguous blocks of (nearly) equal cost that tile [0, n) in order; uniform cost = the equal-height blocks."""
+    bp = tile_shard.balanced_partition
+    for cost, world in (([1] * 135, 8), ([5, 1, 1, 1, 9, 9, 1, 1, 1, 5], 3), ([0, 0, 7, 7, 0, 0], 3), ([0] * 5, 2), ([100, 1, 1, 1], 4), ([3, 1, 4, 1, 5, 9, 2, 6], 1)):
+        parts = bp(cost, world)
+        assert len(parts) == world and parts[0][0] == 0 and parts[-1][1] == len(cost)
+        assert all(parts[i][1] == parts[i + 1][0] and parts[i][0] <= parts[i][1] for i in range(world - 1))
+    sizes = [b - a for a, b in bp([1] * 135, 8)]
+    assert max(sizes) - min(sizes) <= 1
+    heavy = bp([10, 1, 1, 1, 1, 1, 1, 10], 2)
+    assert heavy == [(0, 4), (4, 8)]
+    parts = bp([8, 8, 1, 1, 1, 1, 1, 1, 1, 1], 2)          # the heavy rows end up alone on one rank
+    assert parts[0][1] <= 2
+
+
 def test_two_rank_gloo_gather_and_gradient_allreduce():
     """world_size 2 over gloo: each rank renders its tile rows with the CPU oracle (test-side compute), the
     product's exchange code gathers the strips / all-reduces the partial gradients; rank 0 checks them against
