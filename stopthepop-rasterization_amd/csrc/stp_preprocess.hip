@@ -80,14 +80,29 @@ __device__ __forceinline__ void sh_to_rgb(int idx, int deg, float3 mean, float3 
     }
 }
 
-__global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
+// Rectangles with more tiles than this are walked by the whole 64-lane wave instead of their owner thread (below).
+constexpr int COOP_TILES = 64;
+
+__device__ __forceinline__ int wave_lane() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// number of set bits of a 64-bit ballot below my lane (no shift by the lane index: (1ull << lane) - 1 is the trap of SURVEY 0)
+__device__ __forceinline__ int lanes_below(unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)); }
+__device__ __forceinline__ float bcast_f(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+// What the first half of the per-Gaussian forward hands to the second (everything up to the tile rectangle).
+struct PreStageA {
+    float3 mean, pv;
+    float c3[6];
+    float4 co;
+    float thr, radius;
+    float2 mean2D, rect_dims;
+    int fx0, fy0, fx1, fy1, y0, y1;
+};
+
+// reference preprocessCUDA forward.cu:68-186 up to the rectangle; false where the reference returns (culled)
+__device__ __forceinline__ bool preprocess_stage_a(const PreArgs& a, int idx, PreStageA& o)
 {
 #pragma clang fp contract(off)
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.P) return;
-    a.radii[idx] = 0;
-    a.g.tiles_touched[idx] = 0;
-
     const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
     const float* __restrict__ view = a.view;
     // view-space position; near culling at z <= 0.2 (reference auxiliary.h:211-236)
@@ -97,7 +112,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     pv.z = view[2] * mean.x + view[6] * mean.y + view[10] * mean.z + view[14] * 1.0f;
     if (pv.z <= 0.2f) {
         if (a.prefiltered) atomicOr(&a.g.status[1], 1u);
-        return;
+        return false;
     }
 
     // 3D covariance (reference forward_common.h:149-183) or the precomputed one
@@ -148,10 +163,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
         const float det_orig = cov.m[0][0] * cov.m[1][1] - cov.m[0][1] * cov.m[0][1];
         conv_scale = sqrtf(fmaxf(0.000025f, det_orig / det));
     }
-    if (det == 0.0f) return;
+    if (det == 0.0f) return false;
     const float det_inv = 1.f / det;
     const float4 co = make_float4(c2z * det_inv, -c2y * det_inv, c2x * det_inv, opacity * conv_scale);
-    if (co.w < ALPHA_THRESHOLD) return;
+    if (co.w < ALPHA_THRESHOLD) return false;
 
     // screen-space extent (reference forward.cu:151-164)
     const float thr = log_rounded(co.w / ALPHA_THRESHOLD);
@@ -159,7 +174,7 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     const float mid = 0.5f * (c2x + c2z);
     const float lambda = mid + sqrtf(fmaxf(0.01f, mid * mid - det));
     const float radius = extent * sqrtf(lambda);
-    if (radius <= 0.0f) return;
+    if (radius <= 0.0f) return false;
 
     // projection of the mean (reference auxiliary.h:83-90; the 4x4 product sums (m0 x + m1 y) + (m2 z + m3 w))
     const float* __restrict__ proj = a.proj;
@@ -177,31 +192,92 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     // sharding the window is the whole frame and the two coincide.
     int fx0, fy0, fx1, fy1;
     get_rect(mean2D, rect_dims, a.gx, a.gy, 0, a.gy, fx0, fy0, fx1, fy1);
-    if ((fx1 - fx0) * (fy1 - fy0) == 0) return;
-    const int x0 = fx0, x1 = fx1, y0 = min(max(fy0, a.ty0), fy1), y1 = max(min(fy1, a.ty1), y0);
+    if ((fx1 - fx0) * (fy1 - fy0) == 0) return false;
+    o.mean = mean; o.pv = pv; o.co = co; o.thr = thr; o.radius = radius; o.mean2D = mean2D; o.rect_dims = rect_dims;
+#pragma unroll
+    for (int k = 0; k < 6; k++) o.c3[k] = c3[k];
+    o.fx0 = fx0; o.fy0 = fy0; o.fx1 = fx1; o.fy1 = fy1;
+    o.y0 = min(max(fy0, a.ty0), fy1); o.y1 = max(min(fy1, a.ty1), o.y0);
+    return true;
+}
 
+__global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
+{
+#pragma clang fp contract(off)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    PreStageA o{};
+    bool alive = false;
+    if (idx < a.P) {
+        a.radii[idx] = 0;
+        a.g.tiles_touched[idx] = 0;
+        alive = preprocess_stage_a(a, idx, o);
+    }
+
+    // ---- tiles touched.  With tile-based culling every tile of the rectangle is tested (reference
+    // stopthepop_common.cuh:176-262).  A thread walks a small rectangle itself; a LARGE one (more than COOP_TILES tiles -- a
+    // splat of hundreds of pixels covers thousands) is walked by the whole wave, one tile per lane, its owner's parameters
+    // broadcast as wave-uniform scalars: the counterpart of the reference's warp-cooperative load balancing (:207-259),
+    // built on 64-bit ballots.  Results are identical either way (same test per tile).
+    const int x0 = o.fx0, x1 = o.fx1, y0 = o.y0, y1 = o.y1;
     int tile_count = (x1 - x0) * (y1 - y0);
-    if (a.tile_based_culling) { // reference stopthepop_common.cuh:176-262
+    int full_count = 1;
+    const bool tbc = a.tile_based_culling != 0;
+    const int rect_tiles = (o.fx1 - o.fx0) * (o.fy1 - o.fy0);
+    const bool coop = alive && tbc && a.tile_counts == nullptr && rect_tiles > COOP_TILES;
+    if (alive && tbc && !coop) {
         tile_count = 0;
-        int full_count = 0;
-        for (int y = fy0; y < fy1; y++)
-            for (int x = fx0; x < fx1; x++) {
+        full_count = 0;
+        for (int y = o.fy0; y < o.fy1; y++)
+            for (int x = o.fx0; x < o.fx1; x++) {
                 const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
                 const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
                 float2 mp;
-                const float f = max_contrib_power_rect(co, mean2D, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), mp);
-                const int hit = (f <= thr) ? 1 : 0;
+                const float f = max_contrib_power_rect(o.co, o.mean2D, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), mp);
+                const int hit = (f <= o.thr) ? 1 : 0;
                 full_count += hit;
                 const int mine = (y >= y0 && y < y1) ? hit : 0;
                 tile_count += mine;
                 if (mine && a.tile_counts) atomicAdd(&a.tile_counts[y * a.gx + x], 1u);
             }
-        if (full_count == 0) return;
-    } else if (a.tile_counts) {
+    } else if (alive && !tbc && a.tile_counts) {
         for (int y = y0; y < y1; y++)
             for (int x = x0; x < x1; x++) atomicAdd(&a.tile_counts[y * a.gx + x], 1u);
     }
+    {
+        const int lane = wave_lane();
+        unsigned long long todo = __ballot(coop);
+        while (todo) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const float4 co = make_float4(bcast_f(o.co.x, src), bcast_f(o.co.y, src), bcast_f(o.co.z, src), bcast_f(o.co.w, src));
+            const float2 m2 = make_float2(bcast_f(o.mean2D.x, src), bcast_f(o.mean2D.y, src));
+            const float thr = bcast_f(o.thr, src);
+            const int sx0 = bcast_i(o.fx0, src), sy0 = bcast_i(o.fy0, src), sx1 = bcast_i(o.fx1, src), sy1 = bcast_i(o.fy1, src);
+            const int wy0 = bcast_i(o.y0, src), wy1 = bcast_i(o.y1, src);
+            const int w = sx1 - sx0, n = w * (sy1 - sy0);
+            int full = 0, mine = 0;
+            for (int t0 = 0; t0 < n; t0 += 64) {
+                const int t = t0 + lane;
+                const int ty = t / w, y = sy0 + ty, x = sx0 + (t - ty * w);
+                bool hit = false;
+                if (t < n) {
+                    const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
+                    const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
+                    float2 mp;
+                    hit = max_contrib_power_rect(co, m2, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), mp) <= thr;
+                }
+                full += (int)__popcll(__ballot(hit));
+                mine += (int)__popcll(__ballot(hit && y >= wy0 && y < wy1));
+            }
+            if (lane == src) { full_count = full; tile_count = mine; }
+        }
+    }
+    if (!alive || full_count == 0) return;
 
+    const float3 mean = o.mean, pv = o.pv;
+    const float4 co = o.co;
+    const float2 mean2D = o.mean2D, rect_dims = o.rect_dims;
+    const float radius = o.radius;
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
     // (SH -> RGB is sh_color_kernel's: it runs BEHIND the num_rendered read-back, see stp_forward)
 
@@ -306,72 +382,115 @@ struct DupArgs {
     uint32_t* tile_cursor; // binning by tile counters: next free slot of every tile's segment (nullptr: slots by point_offsets)
 };
 
+// key + write decision of ONE (Gaussian, tile) pair: reference duplicateWithKeys_extended, stopthepop_common.cuh:420-460
+struct DupGaussian { float2 xy; float4 co; float thr; float3 p0, p1, p2; float global_depth; };
+__device__ __forceinline__ bool duplicate_tile(const DupArgs& a, const DupGaussian& g, float3 cam, bool tbc, bool eval_max, bool per_tile_depth,
+                                               int x, int y, uint64_t& key)
+{
+#pragma clang fp contract(off)
+    const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
+    const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
+    float2 max_pos = make_float2(0, 0);
+    float max_fac = 0.0f;
+    if (eval_max) max_fac = max_contrib_power_rect(g.co, g.xy, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), max_pos);
+    float depth = g.global_depth;
+    if (per_tile_depth) { // reference stopthepop_common.cuh:439-449
+        const float2 center = make_float2((tmin.x + tmax.x) * 0.5f, (tmin.y + tmax.y) * 0.5f);
+        const float2 target = (a.sort_order == ORDER_PTD_MAX) ? max_pos : center;
+        const float3 dir = view_ray(a.inv_vp, cam, target.x, target.y, a.W, a.H);
+        depth = fmaxf(0.0f, depth_along_ray(g.p0, g.p1, g.p2, dir) + 8.0f);
+    }
+    key = make_sort_key((uint32_t)(y * a.gx + x), depth);
+    return !tbc || max_fac <= g.thr;
+}
+
 __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
 {
 #pragma clang fp contract(off)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= a.P) return;
-    if (a.radii[idx] <= 0) return;
-    uint32_t off = (idx == 0) ? 0u : a.g.point_offsets[idx - 1];
-    const uint32_t off_to = a.g.point_offsets[idx];
-    const float2 xy = a.g.means2D[idx];
-    const float2 ext = a.g.rects2D[idx];
-    int x0, y0, x1, y1;
-    get_rect(xy, ext, a.gx, a.gy, a.ty0, a.ty1, x0, y0, x1, y1);
-
+    const bool valid = idx < a.P && a.radii[idx] > 0;   // (no early return: the wave's lanes meet again for the large rectangles)
     const bool tbc = a.tile_based_culling != 0;
     const bool per_tile_depth = a.sort_order == ORDER_PTD_CENTER || a.sort_order == ORDER_PTD_MAX;
     const bool eval_max = tbc || a.sort_order == ORDER_PTD_MAX;
-    float4 co = make_float4(0, 0, 0, 0);
-    float thr = 0.0f;
-    if (eval_max) {
-        co = a.g.conic_opacity[idx];
-        thr = log_rounded(co.w / ALPHA_THRESHOLD);
-    }
-    float3 p0 = make_float3(0, 0, 0), p1 = p0, p2 = p0, cam = p0;
-    if (per_tile_depth) {
-        p0 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 0]);
-        p1 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 1]);
-        p2 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 2]);
-        cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
-    }
-    const float global_depth = a.g.depths[idx];
-
-    for (int y = y0; y < y1; y++)
-        for (int x = x0; x < x1; x++) {
-            const float2 tmin = make_float2((float)(x * TILE), (float)(y * TILE));
-            const float2 tmax = make_float2((float)((x + 1) * TILE - 1), (float)((y + 1) * TILE - 1));
-            float2 max_pos = make_float2(0, 0);
-            float max_fac = 0.0f;
-            if (eval_max) max_fac = max_contrib_power_rect(co, xy, tmin, tmax, (float)(TILE - 1), (float)(TILE - 1), max_pos);
-            float depth = global_depth;
-            if (per_tile_depth) { // reference stopthepop_common.cuh:439-449
-                const float2 center = make_float2((tmin.x + tmax.x) * 0.5f, (tmin.y + tmax.y) * 0.5f);
-                const float2 target = (a.sort_order == ORDER_PTD_MAX) ? max_pos : center;
-                const float3 dir = view_ray(a.inv_vp, cam, target.x, target.y, a.W, a.H);
-                depth = fmaxf(0.0f, depth_along_ray(p0, p1, p2, dir) + 8.0f);
-            }
-            const bool write = !tbc || max_fac <= thr;
-            if (write) {
-                const uint32_t tile = (uint32_t)(y * a.gx + x);
-                if (a.tile_cursor) { // straight into the tile's segment; the order inside it is settled by the tile sort
-                    const uint32_t slot = atomicAdd(&a.tile_cursor[tile], 1u);
-                    a.values[slot] = (uint32_t)idx;
-                    a.keys[slot] = make_sort_key(tile, depth);
-                } else if (off < off_to) {
-                    a.values[off] = (uint32_t)idx;
-                    a.keys[off] = make_sort_key(tile, depth);
-                }
-                off++;
-            }
+    uint32_t off = 0, off_to = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    DupGaussian g{};
+    float3 cam = make_float3(0, 0, 0);
+    if (per_tile_depth) cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
+    if (valid) {
+        off = (idx == 0) ? 0u : a.g.point_offsets[idx - 1];
+        off_to = a.g.point_offsets[idx];
+        g.xy = a.g.means2D[idx];
+        const float2 ext = a.g.rects2D[idx];
+        get_rect(g.xy, ext, a.gx, a.gy, a.ty0, a.ty1, x0, y0, x1, y1);
+        if (eval_max) {
+            g.co = a.g.conic_opacity[idx];
+            g.thr = log_rounded(g.co.w / ALPHA_THRESHOLD);
         }
-    if (a.tile_cursor) return; // (entries that preprocess counted but culling dropped -- none, the two tests are the same
-                               //  function -- would be padded by bin_pad_kernel behind the last segment)
-    // pad what the (slightly more generous) preprocess count reserved but culling did not use
-    // (reference stopthepop_common.cuh:503-508, 614-619)
-    for (; off < off_to; off++) {
-        a.values[off] = 0xFFFFFFFFu;
-        a.keys[off] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
+        if (per_tile_depth) {
+            g.p0 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 0]);
+            g.p1 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 1]);
+            g.p2 = f4_xyz(a.g.cov3D_inv[3 * (size_t)idx + 2]);
+        }
+        g.global_depth = a.g.depths[idx];
+    }
+    // A rectangle of more than COOP_TILES tiles is walked by the whole wave (one tile per lane, the owner's data as
+    // wave-uniform scalars, write slots from a ballot prefix count so that the row-major order of the sequential loop is
+    // kept): the counterpart of the reference's warp-cooperative duplication (stopthepop_common.cuh:510-621) on 64 lanes.
+    const bool coop = valid && a.tile_cursor == nullptr && (x1 - x0) * (y1 - y0) > COOP_TILES;
+    if (valid && !coop) {
+        for (int y = y0; y < y1; y++)
+            for (int x = x0; x < x1; x++) {
+                uint64_t key;
+                if (duplicate_tile(a, g, cam, tbc, eval_max, per_tile_depth, x, y, key)) {
+                    if (a.tile_cursor) { // straight into the tile's segment; the order inside it is settled by the tile sort
+                        const uint32_t slot = atomicAdd(&a.tile_cursor[(uint32_t)(key >> 32)], 1u);
+                        a.values[slot] = (uint32_t)idx;
+                        a.keys[slot] = key;
+                    } else if (off < off_to) {
+                        a.values[off] = (uint32_t)idx;
+                        a.keys[off] = key;
+                    }
+                    off++;
+                }
+            }
+        if (!a.tile_cursor) // pad what the (slightly more generous) preprocess count reserved but culling did not use
+            for (; off < off_to; off++) { // (reference stopthepop_common.cuh:503-508, 614-619)
+                a.values[off] = 0xFFFFFFFFu;
+                a.keys[off] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
+            }
+    }
+    const int lane = wave_lane();
+    unsigned long long todo = __ballot(coop);
+    while (todo) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        DupGaussian s;
+        s.xy = make_float2(bcast_f(g.xy.x, src), bcast_f(g.xy.y, src));
+        s.co = make_float4(bcast_f(g.co.x, src), bcast_f(g.co.y, src), bcast_f(g.co.z, src), bcast_f(g.co.w, src));
+        s.thr = bcast_f(g.thr, src);
+        s.p0 = make_float3(bcast_f(g.p0.x, src), bcast_f(g.p0.y, src), bcast_f(g.p0.z, src));
+        s.p1 = make_float3(bcast_f(g.p1.x, src), bcast_f(g.p1.y, src), bcast_f(g.p1.z, src));
+        s.p2 = make_float3(bcast_f(g.p2.x, src), bcast_f(g.p2.y, src), bcast_f(g.p2.z, src));
+        s.global_depth = bcast_f(g.global_depth, src);
+        const int sx0 = bcast_i(x0, src), sy0 = bcast_i(y0, src), sx1 = bcast_i(x1, src), sy1 = bcast_i(y1, src);
+        const uint32_t s_to = (uint32_t)bcast_i((int)off_to, src), s_idx = (uint32_t)bcast_i(idx, src);
+        uint32_t base = (uint32_t)bcast_i((int)off, src);
+        const int w = sx1 - sx0, n = w * (sy1 - sy0);
+        for (int t0 = 0; t0 < n; t0 += 64) {
+            const int t = t0 + lane;
+            const int ty = t / w;
+            uint64_t key = 0;
+            const bool wr = t < n && duplicate_tile(a, s, cam, tbc, eval_max, per_tile_depth, sx0 + (t - ty * w), sy0 + ty, key);
+            const unsigned long long wm = __ballot(wr);
+            const uint32_t slot = base + (uint32_t)lanes_below(wm);
+            if (wr && slot < s_to) { a.values[slot] = s_idx; a.keys[slot] = key; }
+            base += (uint32_t)__popcll(wm);
+        }
+        for (uint32_t p = base + (uint32_t)lane; p < s_to; p += 64u) {
+            a.values[p] = 0xFFFFFFFFu;
+            a.keys[p] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
+        }
     }
 }
 

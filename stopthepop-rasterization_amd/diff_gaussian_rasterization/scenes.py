@@ -180,6 +180,9 @@ _CONFIGS = {
     "C3": dict(P=3_000_000, W=1920, H=1080, sigma_min=0.5, sigma_max=5.0, seed=3),
     "C4": dict(P=1_000_000, W=3840, H=2160, sigma_min=1.0, sigma_max=12.0, seed=4),
     "C5": dict(P=6_000_000, W=1600, H=1063, sigma_min=0.5, sigma_max=5.0, seed=5),
+    # not a BASELINE config: LARGE splats (pixel sigma up to 200, i.e. rectangles of hundreds to thousands of tiles per
+    # Gaussian) -- the regime the reference's warp-cooperative tile loops exist for (stopthepop_common.cuh:207-259, 510-621)
+    "L1": dict(P=20_000, W=1920, H=1080, sigma_min=10.0, sigma_max=200.0, seed=6, opacity_range=(0.02, 0.3)),
 }
 
 

@@ -291,6 +291,22 @@ def test_backward_after_a_render_depth_forward_is_memory_safe(sd):
             assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
 
 
+LARGE = dict(P=300, W=640, H=480, sigma_min=10.0, sigma_max=200.0, seed=61, camera="orbit", opacity_range=(0.02, 0.3))
+
+
+@pytest.mark.parametrize("sd", [settings_dict(**FULL_STP), settings_dict(3), settings_dict(0, order=2, rect=True, tbc=True), settings_dict(2, per_pixel=8, tbc=True)],
+                         ids=["full_stp", "hier_min", "global_ptd_tbc", "kbuffer_tbc"])
+def test_large_splats_take_the_wave_cooperative_tile_loops(sd):
+    """Pixel sigmas up to 200: rectangles of hundreds to over a thousand tiles per Gaussian -- more than COOP_TILES = 64, so
+    preprocess_kernel's tile-based-culling count and duplicate_kernel's key emission run wave-cooperatively (the counterpart
+    of the reference's load balancing, stopthepop_common.cuh:207-259, 510-621).  Same bit-exact checks as everywhere."""
+    sc = scenes.make_scene(**LARGE)
+    g, f = check_against_oracle(sc, sd)
+    assert int(g.geom_array("tiles_touched").view(np.uint32).max()) > 64          # the cooperative path is what ran
+    assert np.array_equal(g.binning_array("keys_unsorted"), f.array("keys_unsorted"))       # emission order included
+    assert np.array_equal(g.binning_array("point_list_unsorted"), f.array("values_unsorted"))
+
+
 @pytest.mark.parametrize("name", ["c1_global", "dense_hier_full", "dense_kbuffer"])
 def test_golden_fixtures(name):
     from golden.make_golden import CASES
