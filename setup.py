@@ -1,0 +1,35 @@
+"""pip-installable form of the drop-in package (the reference is `pip install`-able too, reference setup.py).
+
+    pip install --no-build-isolation -e .        # or: pip install --no-build-isolation .
+
+builds libstp_raster.so with hipcc for gfx950 (make -C stopthepop-rasterization_amd/csrc; no torch C++ extension,
+no hipify pass) and installs the package `diff_gaussian_rasterization` with the library as package data.
+The repository's test-side directories (oracle/, tests/, tools/) are not installed."""
+import os
+import subprocess
+
+from setuptools import setup
+from setuptools.command.build_py import build_py
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG_PARENT = "stopthepop-rasterization_amd"
+
+
+class BuildWithLibrary(build_py):
+    def run(self):
+        jobs = str(min(8, os.cpu_count() or 1))
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, PKG_PARENT, "csrc"), "-j", jobs, "ARCH=gfx950"])
+        super().run()
+
+
+setup(
+    name="diff_gaussian_rasterization",
+    version="0.2.0",
+    description="MI355X-native sorted Gaussian-splat rasterizer behind the StopThePop diff_gaussian_rasterization API",
+    packages=["diff_gaussian_rasterization"],
+    package_dir={"": PKG_PARENT},
+    package_data={"diff_gaussian_rasterization": ["libstp_raster.so"]},
+    cmdclass={"build_py": BuildWithLibrary},
+    python_requires=">=3.9",
+    install_requires=[],   # torch (ROCm build) is expected in the environment, as with the reference
+)

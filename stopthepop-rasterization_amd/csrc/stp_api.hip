@@ -35,10 +35,11 @@ struct StageTimer {
     int cur = 0;
     double sum[6] = {};
     long cnt[6] = {};
+    long failures = 0; // hipEventCreate / Record failures since the last reset (surfaced by stp_timing_read)
     void ensure()
     {
         if (created) return;
-        for (auto& s : sets) { for (auto& e : s.ev) (void)hipEventCreate(&e); for (auto& h : s.have) h = false; s.used = false; }
+        for (auto& s : sets) { for (auto& e : s.ev) if (hipEventCreate(&e) != hipSuccess) failures++; for (auto& h : s.have) h = false; s.used = false; }
         created = true;
     }
     void harvest(Set& s)
@@ -73,7 +74,7 @@ struct StageTimer {
     {
         if (!g_timing) return;
         ensure();
-        (void)hipEventRecord(sets[cur].ev[i], st);
+        if (hipEventRecord(sets[cur].ev[i], st) != hipSuccess) { failures++; return; }
         sets[cur].have[i] = true;
     }
     void reset()
@@ -81,9 +82,25 @@ struct StageTimer {
         if (created) for (auto& s : sets) { for (auto& h : s.have) h = false; s.used = false; }
         for (auto& v : sum) v = 0.0;
         for (auto& c : cnt) c = 0;
+        failures = 0;
     }
 };
-static StageTimer g_timer;
+// One timer per device (its events live on that device; a backward is attributed to the latest forward OF ITS DEVICE), all
+// behind one mutex: timing is a debugging aid, the lock is uncontended in the single-threaded use the reference knows.
+static StageTimer g_timers[32];
+static std::mutex g_timer_mutex;
+static StageTimer& current_timer()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 32) d = 0;
+    return g_timers[d];
+}
+struct TimerFacade { // keeps the call sites short: g_timer.mark(...) locks and forwards to the current device's timer
+    void begin_forward() { if (!g_timing) return; std::lock_guard<std::mutex> l(g_timer_mutex); current_timer().begin_forward(); }
+    void begin_backward() { if (!g_timing) return; std::lock_guard<std::mutex> l(g_timer_mutex); current_timer().begin_backward(); }
+    void mark(int i, hipStream_t st) { if (!g_timing) return; std::lock_guard<std::mutex> l(g_timer_mutex); current_timer().mark(i, st); }
+};
+static TimerFacade g_timer;
 
 static int fail(int code, const std::string& msg)
 {
@@ -316,19 +333,23 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
 
 void stp_timing_enable(int enabled)
 {
+    std::lock_guard<std::mutex> l(g_timer_mutex);
     g_timing = enabled != 0;
-    if (g_timing) g_timer.reset();
+    if (g_timing) for (auto& t : g_timers) t.reset();
 }
 
-int stp_timing_read(float* ms6)
+int stp_timing_read(float* ms6) // the calling thread's current device
 {
     if (!ms6) return fail(STP_ERR_INVALID_ARGUMENT, "null output");
     for (int i = 0; i < 6; i++) ms6[i] = -1.0f;
-    if (!g_timer.created) return 0;
-    for (auto& s : g_timer.sets) g_timer.harvest(s);
+    std::lock_guard<std::mutex> l(g_timer_mutex);
+    StageTimer& t = current_timer();
+    if (!t.created) return 0;
+    for (auto& s : t.sets) t.harvest(s);
     // 0 Preprocess (+scan+read-back), 1 Duplicate, 2 Sort (+ranges), 3 Render, 4 BwdRender, 5 BwdPreprocess
     for (int i = 0; i < 6; i++)
-        if (g_timer.cnt[i] > 0) ms6[i] = (float)(g_timer.sum[i] / (double)g_timer.cnt[i]);
+        if (t.cnt[i] > 0) ms6[i] = (float)(t.sum[i] / (double)t.cnt[i]);
+    if (t.failures > 0) return fail(STP_ERR_HIP, "stage timer: " + std::to_string(t.failures) + " hipEvent create/record call(s) failed; timings are incomplete");
     return 0;
 }
 
@@ -409,6 +430,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     //                     into its tile's segment through an atomic cursor, then the same per-tile sort.  Measured SLOWER on
     //                     MI355X (the 2 x R device-scope atomics cost more than the two radix passes they replace: C2
     //                     preprocess + duplicate + sort 0.54 ms against 0.50 ms); kept selectable and tested.
+    // (STP_SORT is read ONCE, at the first forward of the process: it selects code paths, not per-call behaviour)
     static const char* const sort_env = std::getenv("STP_SORT");
     static const bool tile_local_sort = !(sort_env && std::strcmp(sort_env, "radix") == 0);
     static const bool atomic_bin = sort_env && std::strcmp(sort_env, "counters") == 0;
