@@ -61,7 +61,8 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
     entry[k] = e
 allj[label] = entry
 allj["_csrc_sha256"] = stamp
-allj["_taken"] = f"rocprofv3 PMC passes of {os.path.basename(os.path.normpath(d))} (profiles/), csrc sha256 {stamp[:12]}"
+allj.setdefault("_dirs", {})[label] = os.path.basename(os.path.normpath(d))
+allj["_taken"] = "rocprofv3 PMC passes " + ", ".join(f"profiles/{v} ({k})" for k, v in sorted(allj["_dirs"].items())) + f"; csrc sha256 {stamp[:12]}"
 allj["_note"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), mean per dispatch; FETCH_SIZE x2 (gfx950), KiB -> bytes; SQ_* from pass 1"
 json.dump(allj, open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, "with", len(entry), "kernels for", label)
