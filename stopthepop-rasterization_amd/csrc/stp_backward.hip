@@ -278,7 +278,9 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
     if (have_sh) {
         const float* __restrict__ src = a.shs + (size_t)base * row_len;
         const int total = rows * row_len;
-        if ((row_len & 3) == 0) {
+        if (row_len == 48 && rows == 256) { // SH degree 3 (M = 16), full block: every load in flight at once (stp_device.h)
+            stage_rows_in<256, 48>(src, s_rows, tid);
+        } else if ((row_len & 3) == 0) {
             for (int f = 4 * tid; f < total; f += 4 * 256) {
                 const float4 v = *reinterpret_cast<const float4*>(src + f);
                 const int r = f / row_len, j = f - r * row_len;
@@ -317,7 +319,9 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
         __syncthreads();
         float* __restrict__ dst = a.dL_dsh + (size_t)base * row_len;
         const int total = rows * row_len;
-        if ((row_len & 3) == 0) {
+        if (row_len == 48 && rows == 256) {
+            stage_rows_out<256, 48>(dst, s_rows, tid);
+        } else if ((row_len & 3) == 0) {
             for (int f = 4 * tid; f < total; f += 4 * 256) {
                 const int r = f / row_len, j = f - r * row_len;
                 const float* d = s_rows + r * row_stride + j;

@@ -331,4 +331,46 @@ __device__ __forceinline__ uint64_t make_sort_key(uint32_t tile, float depth) //
     return ((uint64_t)tile << 32) | (uint64_t)__float_as_uint(depth);
 }
 
+
+// Workgroup-cooperative staging of BLOCK rows of ROWLEN floats (ROWLEN % 4 == 0) from global memory into LDS rows padded to
+// ROWLEN + 1 words, for a FULL block: all of a thread's 16-byte loads are issued before the first LDS write (the generic
+// loop with a run-time row length computes an integer division per iteration and ends up with ONE load in flight per
+// thread: measured 3.0 TB/s for the SH rows; the unrolled form keeps ROWLEN / 4 in flight).
+template <int BLOCK, int ROWLEN>
+__device__ __forceinline__ void stage_rows_load(const float* __restrict__ src, int tid, float4 (&v)[ROWLEN / 4])
+{
+#pragma unroll
+    for (int k = 0; k < ROWLEN / 4; k++) v[k] = reinterpret_cast<const float4*>(src)[tid + k * BLOCK];
+}
+template <int BLOCK, int ROWLEN>
+__device__ __forceinline__ void stage_rows_store(float* __restrict__ s_rows, int tid, const float4 (&v)[ROWLEN / 4])
+{
+#pragma unroll
+    for (int k = 0; k < ROWLEN / 4; k++) {
+        const int f = 4 * (tid + k * BLOCK);
+        const int r = f / ROWLEN, j = f - r * ROWLEN;
+        float* d = s_rows + r * (ROWLEN + 1) + j;
+        d[0] = v[k].x; d[1] = v[k].y; d[2] = v[k].z; d[3] = v[k].w;
+    }
+}
+template <int BLOCK, int ROWLEN>
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, float* __restrict__ s_rows, int tid)
+{
+    float4 v[ROWLEN / 4];
+    stage_rows_load<BLOCK, ROWLEN>(src, tid, v);
+    stage_rows_store<BLOCK, ROWLEN>(s_rows, tid, v);
+}
+template <int BLOCK, int ROWLEN>
+__device__ __forceinline__ void stage_rows_out(float* __restrict__ dst, const float* __restrict__ s_rows, int tid)
+{
+    constexpr int N = ROWLEN / 4;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int f = 4 * (tid + k * BLOCK);
+        const int r = f / ROWLEN, j = f - r * ROWLEN;
+        const float* d = s_rows + r * (ROWLEN + 1) + j;
+        reinterpret_cast<float4*>(dst)[tid + k * BLOCK] = make_float4(d[0], d[1], d[2], d[3]);
+    }
+}
+
 } // namespace stp

@@ -91,7 +91,8 @@ __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn
 
 // What the first half of the per-Gaussian forward hands to the second (everything up to the tile rectangle).
 struct PreStageA {
-    float3 mean, pv;
+    float3 mean, pv, sc;
+    float4 q;
     float c3[6];
     float4 co;
     float thr, radius;
@@ -103,7 +104,21 @@ struct PreStageA {
 __device__ __forceinline__ bool preprocess_stage_a(const PreArgs& a, int idx, PreStageA& o)
 {
 #pragma clang fp contract(off)
+    // every per-Gaussian input up front, before the first test can branch: the loads are in flight together (one memory
+    // latency) instead of one after each early-out
     const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
+    const float opacity = a.opacities[idx];
+    float3 sc_in = make_float3(0.0f, 0.0f, 0.0f);
+    float4 q_in = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float c3_in[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c3_in[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+    }
+    if (a.scales != nullptr && a.rotations != nullptr) { // (also WITH a precomputed covariance: Sigma^-1 is always built from these, forward.cu:208-220)
+        sc_in = make_float3(a.scales[3 * (size_t)idx], a.scales[3 * (size_t)idx + 1], a.scales[3 * (size_t)idx + 2]);
+        q_in = reinterpret_cast<const float4*>(a.rotations)[idx];
+    }
     const float* __restrict__ view = a.view;
     // view-space position; near culling at z <= 0.2 (reference auxiliary.h:211-236)
     float3 pv;
@@ -119,10 +134,10 @@ __device__ __forceinline__ bool preprocess_stage_a(const PreArgs& a, int idx, Pr
     float c3[6];
     if (a.cov3D_precomp != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) c3[k] = a.cov3D_precomp[6 * (size_t)idx + k];
+        for (int k = 0; k < 6; k++) c3[k] = c3_in[k];
     } else {
-        const float3 sc = make_float3(a.scales[3 * (size_t)idx], a.scales[3 * (size_t)idx + 1], a.scales[3 * (size_t)idx + 2]);
-        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float3 sc = sc_in;
+        const float4 q = q_in;
         const Mat3 S = mat_diag(a.scale_modifier * sc.x, a.scale_modifier * sc.y, a.scale_modifier * sc.z);
         const Mat3 Mm = mat_mul(S, quat_to_mat(q));
         const Mat3 Sig = mat_mul(mat_transpose(Mm), Mm);
@@ -154,7 +169,6 @@ __device__ __forceinline__ bool preprocess_stage_a(const PreArgs& a, int idx, Pr
     const Mat3 cov = mat_mul(mat_mul(mat_transpose(T), mat_transpose(Vrk)), T);
 
     // low-pass dilation, optional Mip-Splatting opacity scaling (reference forward_common.h:108-131)
-    const float opacity = a.opacities[idx];
     float c2x = cov.m[0][0], c2y = cov.m[0][1], c2z = cov.m[1][1];
     c2x += 0.3f; c2z += 0.3f;
     const float det = c2x * c2z - c2y * c2y;
@@ -193,6 +207,7 @@ __device__ __forceinline__ bool preprocess_stage_a(const PreArgs& a, int idx, Pr
     int fx0, fy0, fx1, fy1;
     get_rect(mean2D, rect_dims, a.gx, a.gy, 0, a.gy, fx0, fy0, fx1, fy1);
     if ((fx1 - fx0) * (fy1 - fy0) == 0) return false;
+    o.sc = sc_in; o.q = q_in;
     o.mean = mean; o.pv = pv; o.co = co; o.thr = thr; o.radius = radius; o.mean2D = mean2D; o.rect_dims = rect_dims;
 #pragma unroll
     for (int k = 0; k < 6; k++) o.c3[k] = c3[k];
@@ -281,9 +296,9 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
     // (SH -> RGB is sh_color_kernel's: it runs BEHIND the num_rendered read-back, see stp_forward)
 
-    if (a.g.cov3D_inv != nullptr) { // reference forward.cu:208-220, stopthepop_common.cuh:13-41
-        const float3 sc = make_float3(a.scales[3 * (size_t)idx], a.scales[3 * (size_t)idx + 1], a.scales[3 * (size_t)idx + 2]);
-        const float4 q = reinterpret_cast<const float4*>(a.rotations)[idx];
+    if (a.g.cov3D_inv != nullptr) { // reference forward.cu:208-220, stopthepop_common.cuh:13-41 (needs scales + rotations: stp_forward checks)
+        const float3 sc = o.sc;
+        const float4 q = o.q;
         const Mat3 S = mat_diag(1.f / (a.scale_modifier * fmaxf(1e-3f, sc.x)), 1.f / (a.scale_modifier * fmaxf(1e-3f, sc.y)),
                                 1.f / (a.scale_modifier * fmaxf(1e-3f, sc.z)));
         const Mat3 Mm = mat_mul(S, quat_to_mat(q));
@@ -336,35 +351,48 @@ struct ShArgs {
     float* rgb;
 };
 
-__global__ void __launch_bounds__(256) sh_color_kernel(const ShArgs a)
+#ifndef STP_SH_BLOCK
+#define STP_SH_BLOCK 256
+#endif
+constexpr int SH_BLOCK = STP_SH_BLOCK; // Gaussians (= threads) per workgroup: its LDS staging area is SH_BLOCK x (3M + 1) words
+
+__global__ void __launch_bounds__(SH_BLOCK) sh_color_kernel(const ShArgs a)
 {
-    extern __shared__ float s_rows[]; // [256][3M + 1]
+    extern __shared__ float s_rows[]; // [SH_BLOCK][3M + 1]
     const int tid = (int)threadIdx.x;
-    const int base = (int)blockIdx.x * 256;
+    const int base = (int)blockIdx.x * SH_BLOCK;
     const int idx = base + tid;
-    const int rows = min(256, a.P - base);
+    const int rows = min(SH_BLOCK, a.P - base);
     const int row_len = 3 * a.M, row_stride = row_len + 1;
-    // (no early exit on "nobody visible": it would put the radii load in front of the coefficient loads -- two dependent
-    // memory latencies per workgroup instead of one; the loads below do not wait for this one)
-    const int my_radius = idx < a.P ? a.radii[idx] : 0;
+    // Order of the loads matters: the coefficient rows FIRST (twelve 16-byte loads per thread in flight), the Gaussian's
+    // radius and mean behind them -- one memory latency per workgroup instead of three dependent ones.  (No early exit on
+    // "nobody visible" either: it would put the radius in front again.)
     const float* __restrict__ src = a.shs + (size_t)base * row_len;
     const int total = rows * row_len;
-    if ((row_len & 3) == 0) {
-        for (int f = 4 * tid; f < total; f += 4 * 256) {
+    const bool fast = row_len == 48 && rows == SH_BLOCK; // SH degree 3 (M = 16), full block
+    float4 v48[12];
+    if (fast) stage_rows_load<SH_BLOCK, 48>(src, tid, v48);
+    const int ic = min(idx, a.P - 1); // (clamped, unconditional loads: no branch between them, both in flight together)
+    const int radius_ic = a.radii[ic];
+    const float3 mean = make_float3(a.means3D[3 * (size_t)ic], a.means3D[3 * (size_t)ic + 1], a.means3D[3 * (size_t)ic + 2]);
+    const int my_radius = idx < a.P ? radius_ic : 0;
+    if (fast) {
+        stage_rows_store<SH_BLOCK, 48>(s_rows, tid, v48);
+    } else if ((row_len & 3) == 0) {
+        for (int f = 4 * tid; f < total; f += 4 * SH_BLOCK) {
             const float4 v = *reinterpret_cast<const float4*>(src + f);
             const int r = f / row_len, j = f - r * row_len;
             float* d = s_rows + r * row_stride + j;
             d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
         }
     } else {
-        for (int f = tid; f < total; f += 256) {
+        for (int f = tid; f < total; f += SH_BLOCK) {
             const int r = f / row_len, j = f - r * row_len;
             s_rows[r * row_stride + j] = src[f];
         }
     }
     __syncthreads();
     if (my_radius > 0) {
-        const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
         const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
         sh_to_rgb(idx, a.D, mean, cam, s_rows + tid * row_stride, a.clamped, a.rgb);
     }
@@ -554,12 +582,12 @@ hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const i
     if (f.colors_precomp != nullptr || f.shs == nullptr || f.M <= 0) return hipSuccess; // reference forward.cu:200: precomputed colours win
     ShArgs a;
     a.P = f.P; a.D = f.D; a.M = f.M; a.means3D = f.means3D; a.shs = f.shs; a.cam = f.cam_pos; a.radii = radii; a.clamped = g.clamped; a.rgb = g.rgb;
-    const size_t lds = (size_t)256 * (3 * a.M + 1) * sizeof(float);
+    const size_t lds = (size_t)SH_BLOCK * (3 * a.M + 1) * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sh_color_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sh_color_kernel, dim3((f.P + 255) / 256), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(sh_color_kernel, dim3((f.P + SH_BLOCK - 1) / SH_BLOCK), dim3(SH_BLOCK), lds, st, a);
     return hipGetLastError();
 }
 
