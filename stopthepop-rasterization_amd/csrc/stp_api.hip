@@ -420,7 +420,6 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
     ImageState img = carve_image(img_ptr, N, T, with_log, nullptr);
-    STP_TRY(hipMemsetAsync(img.tile_flags, with_log ? 0 : 0xFF, T * sizeof(uint32_t), st), "memset tile flags");
 
     // How the (tile, depth) order is established:
     //   default           device-wide radix sort on the tile bits only (two passes), then the tile's own workgroup sorts its
@@ -437,8 +436,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
 
     g_timer.begin_forward();
     g_timer.mark(0, st);
-    STP_TRY(hipMemsetAsync(g.status, 0, 64 * sizeof(uint32_t), st), "memset status");
-    if (atomic_bin) STP_TRY(hipMemsetAsync(img.tile_counts, 0, T * sizeof(uint32_t), st), "memset tile counters");
+    STP_TRY(launch_frame_init(g, img, (int)T, with_log, atomic_bin, st), "frame init launch");
     STP_TRY(launch_preprocess(f, g, radii, atomic_bin ? img.tile_counts : nullptr, st), "preprocess launch");
     STP_DEBUG_SYNC("preprocess");
     STP_TRY(launch_scan(f, g, st), "inclusive scan");

@@ -143,6 +143,7 @@ struct BackwardParams {
 
 // ---- launchers (one per stage; each returns hipSuccess or the launch error) ----
 hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, uint32_t* tile_counts, hipStream_t st); // tile_counts: nullptr = do not count per tile
+hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int T, bool with_log, bool tile_counters, hipStream_t st); // status, ranges, tile flags (+ tile counters)
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, hipStream_t st);

@@ -605,11 +605,33 @@ hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, u
     return hipGetLastError();
 }
 
+// One launch for the three small clears of a forward (each hipMemsetAsync is a 5 us fill kernel of its own): the status
+// words, the tile ranges (reference rasterizer_impl.cu:354) and the tile flags (0 = "this tile's log is valid", all ones =
+// "the forward recorded no log", see carve_image).
+__global__ void __launch_bounds__(256) frame_init_kernel(uint32_t* __restrict__ status, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_flags,
+                                                          uint32_t flag_value, uint32_t* __restrict__ tile_counts, int T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 64) status[i] = 0u;
+    if (i < T) {
+        ranges[i] = make_uint2(0u, 0u);
+        tile_flags[i] = flag_value;
+        if (tile_counts) tile_counts[i] = 0u;
+    }
+}
+
+hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int T, bool with_log, bool tile_counters, hipStream_t st)
+{
+    const int n = T > 64 ? T : 64;
+    hipLaunchKernelGGL(frame_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g.status, img.ranges, img.tile_flags, with_log ? 0u : 0xFFFFFFFFu,
+                       tile_counters ? img.tile_counts : nullptr, T);
+    return hipGetLastError();
+}
+
 hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st)
 {
     const size_t T = (size_t)f.gx * f.gy;
-    hipError_t e = hipMemsetAsync(img.ranges, 0, T * sizeof(uint2), st); // reference rasterizer_impl.cu:354
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess; // (the ranges were zeroed by frame_init_kernel)
     if (R > 0) {
         hipLaunchKernelGGL(tile_ranges_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, b.keys, img.ranges, (uint32_t)T);
         e = hipGetLastError();
