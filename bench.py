@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--no-tile-shard-probe", action="store_true",
                     help="N > 1 with --shard frames: do NOT additionally time one frame sharded by tile row over all ranks (the \"tile_shard\" "
                          "object of the JSON line; a fault in it degrades to an error field, the headline stands on its own)")
+    ap.add_argument("--probe-timeout", type=float, default=120.0, help="seconds the tile-row probe may take before the headline is printed without it")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalidates the headline number)")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps (device clock ramp)")
@@ -262,39 +263,7 @@ def main():
     value = frames_per_step * args.steps / dt
     ms_per_step = 1000.0 * dt / args.steps
 
-    # auxiliary measurement (N > 1, or --force-shard handled above): one frame sharded by tile row over all ranks
-    tile_probe = None
-    if world > 1 and not sharded and not args.no_tile_shard_probe:
-        try:
-            r2 = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
-
-            def step2():
-                for x in leaves:
-                    if x is not None and x.grad is not None:
-                        x.grad = None
-                color, _ = r2(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
-                if not fwd_only:
-                    (color * w_img).sum().backward()
-
-            k2 = max(1, min(args.steps, 10))
-            for _ in range(2):
-                step2()
-            barrier()
-            t2 = time.perf_counter()
-            for _ in range(k2):
-                step2()
-            barrier()
-            dt2 = time.perf_counter() - t2
-            tt2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-            dt2 = float(tt2.item())
-            tile_probe = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
-                          "scaling": "strong", "parallelism": f"tilerows{world}",
-                          "exchange": "three channel segments per peer sent straight into rank 0's frame (grouped RCCL send/recv) + all-reduce of 36 B per Gaussian"}
-        except Exception as ex:  # the headline above stands on its own
-            tile_probe = {"error": repr(ex)[:300]}
-
-    if rank == 0:
+    def build_out():
         # measured sizes for the byte models
         radii = state["radii"]
         P = scene.P
@@ -379,6 +348,59 @@ def main():
                            "insts_per_pair": round(64.0 * prof["SQ_INSTS_VALU"] / B, 1) if B else None,
                            "lane_util": round(prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"] / 64.0, 3),
                            "source": prof_note}
+        return out, es
+
+    out = None
+    if rank == 0:
+        out, _ = build_out()
+
+    # auxiliary measurement (N > 1): one frame sharded by tile row over all ranks.  The headline `out` is complete before it
+    # starts, and a watchdog prints it with an error field should the exchange hang (it has never run on 8 GPUs by us).
+    tile_probe = None
+    if world > 1 and not sharded and not args.no_tile_shard_probe:
+        import threading
+
+        def bail():
+            if rank == 0:
+                o = dict(out)
+                o["tile_shard"] = {"error": f"timed out after {args.probe_timeout:.0f} s: the tile-row exchange did not complete; the headline is unaffected"}
+                os.write(result_fd, (json.dumps(o) + "\n").encode())
+            os._exit(0)
+
+        watchdog = threading.Timer(args.probe_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+        try:
+            r2 = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
+
+            def step2():
+                for x in leaves:
+                    if x is not None and x.grad is not None:
+                        x.grad = None
+                color, _ = r2(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
+                if not fwd_only:
+                    (color * w_img).sum().backward()
+
+            k2 = max(1, min(args.steps, 10))
+            for _ in range(2):
+                step2()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(k2):
+                step2()
+            barrier()
+            dt2 = time.perf_counter() - t2
+            tt2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
+            dt2 = float(tt2.item())
+            tile_probe = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
+                          "scaling": "strong", "parallelism": f"tilerows{world}",
+                          "exchange": "three channel segments per peer sent straight into rank 0's frame (grouped RCCL send/recv) + all-reduce of 36 B per Gaussian"}
+        except Exception as ex:  # the headline above stands on its own
+            tile_probe = {"error": repr(ex)[:300]}
+        watchdog.cancel()
+
+    if rank == 0:
         if tile_probe is not None:
             out["tile_shard"] = tile_probe
         if world == 1 and not args.no_cpu_baseline:
