@@ -134,7 +134,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "L1"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "L1", "C2L"])
     ap.add_argument("--variant", default="full", choices=["full", "min"])
     ap.add_argument("--shard", default=None, choices=["tilerows", "frames"],
                     help="N > 1: what the ranks share.  Default: tilerows for C4 (BASELINE's 4K serving configuration IS the tile-row shard "

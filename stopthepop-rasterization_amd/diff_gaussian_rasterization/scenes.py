@@ -96,7 +96,10 @@ def look_at_view(eye, target, up=(0.0, -1.0, 0.0)) -> np.ndarray:
 
 def make_scene(P: int, W: int, H: int, sigma_min: float, sigma_max: float, seed: int,
                use_sh: bool = True, camera: str = "origin", z_range=(2.0, 12.0),
-               opacity_range=(0.05, 0.6), with_grad_image: bool = True) -> Scene:
+               opacity_range=(0.05, 0.6), with_grad_image: bool = True, clusters=None) -> Scene:
+    """clusters = (count, fraction, spread): `fraction` of the Gaussians are gathered around `count` random screen positions
+    with a normal spread of `spread` x the frame size (a lumpy scene: tile lists and per-pixel blend counts far above the
+    homogeneous average in the clusters, empty sky between them); None = homogeneous."""
     tanfovy = 0.5
     tanfovx = 0.5 * W / H
     focal_x = W / (2.0 * tanfovx)
@@ -104,6 +107,14 @@ def make_scene(P: int, W: int, H: int, sigma_min: float, sigma_max: float, seed:
 
     u = uniform(seed, 1, P) * 2.0 - 1.0
     v = uniform(seed, 2, P) * 2.0 - 1.0
+    if clusters is not None:
+        n_c, frac, spread = int(clusters[0]), float(clusters[1]), float(clusters[2])
+        member = uniform(seed, 30, P) < frac
+        which = np.minimum((uniform(seed, 31, P) * n_c).astype(np.int64), n_c - 1)
+        cu = uniform(seed, 32, n_c) * 1.6 - 0.8
+        cv = uniform(seed, 33, n_c) * 1.6 - 0.8
+        u = np.where(member, cu[which] + 2.0 * spread * normal(seed, 34, P), u)
+        v = np.where(member, cv[which] + 2.0 * spread * normal(seed, 35, P), v)
     z = z_range[0] + (z_range[1] - z_range[0]) * uniform(seed, 3, P)
     x = u * 1.05 * tanfovx * z
     y = v * 1.05 * tanfovy * z
@@ -182,6 +193,9 @@ _CONFIGS = {
     "C5": dict(P=6_000_000, W=1600, H=1063, sigma_min=0.5, sigma_max=5.0, seed=5),
     # not a BASELINE config: LARGE splats (pixel sigma up to 200, i.e. rectangles of hundreds to thousands of tiles per
     # Gaussian) -- the regime the reference's warp-cooperative tile loops exist for (stopthepop_common.cuh:207-259, 510-621)
+    # not a BASELINE config: C2's Gaussians, 40 % of them gathered in 12 clusters (what a trained scene looks like more than
+    # the homogeneous C2 does): long tile lists, pixels with hundreds of blends, blend-log overflow
+    "C2L": dict(P=1_000_000, W=1920, H=1080, sigma_min=0.7, sigma_max=7.0, seed=2, clusters=(12, 0.4, 0.03)),
     "L1": dict(P=20_000, W=1920, H=1080, sigma_min=10.0, sigma_max=200.0, seed=6, opacity_range=(0.02, 0.3)),
 }
 
