@@ -28,3 +28,6 @@ rounds = sum(out[1:5])
 print(f"{variant}: consumption rounds {rounds} ({rounds / 32640:.1f} per wave); by participating rows 1/2/3/4: "
       f"{out[1]/rounds:.3f} {out[2]/rounds:.3f} {out[3]/rounds:.3f} {out[4]/rounds:.3f}; mean rows {sum(i*out[i] for i in range(1,5))/rounds:.2f}; "
       f"live lanes per round {out[8]/rounds:.1f}; draining rounds {out[9]/rounds:.3f}")
+if out[10]:
+    print(f"head pre-test: {out[10]} candidates shown (per quad), {out[11]} kept ({out[11]/out[10]:.3f}); {out[12]} group steps "
+          f"({out[12] / 32640:.1f} per wave) carrying {out[13]} candidates = {out[13]/out[12]/64:.3f} of their 64 slots; {out[14]/out[12]:.3f} of them in the final drain")
