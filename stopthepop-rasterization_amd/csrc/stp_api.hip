@@ -222,6 +222,7 @@ static void fill_frame(FrameParams& f, int P, int D, int M, const float* backgro
     f.background = background; f.means3D = means3D; f.shs = shs; f.colors_precomp = colors_precomp; f.opacities = opacities;
     f.scales = scales; f.rotations = rotations; f.cov3D_precomp = cov3D_precomp; f.viewmatrix = viewmatrix; f.projmatrix = projmatrix;
     f.inv_viewprojmatrix = inv_viewprojmatrix; f.cam_pos = cam_pos; f.prefiltered = prefiltered;
+    f.wild_cov = 1; // (until the forward has read the status word: the kernels with the domain check)
 }
 
 } // namespace stp
@@ -468,6 +469,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");
     const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
     if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+    f.wild_cov = (host_status[1] & 2u) ? 1 : 0;
     const int R = (int)host_status[0];
     g_last_R[mb.device].store((uint32_t)R, std::memory_order_relaxed);
     STP_DEBUG_SYNC("SH colour");

@@ -178,12 +178,18 @@ __device__ __forceinline__ float log_rounded(float x) { return (float)log((doubl
 // (tools/numerics_probe.hip checks all 2.1e9 positive normal floats on the device: the only mismatches are the
 // two top binades, where 1/x is subnormal).  Outside that domain (never seen; NaN and 0 included) the whole
 // wave takes the division instead, so the result is the same everywhere.
-__device__ __forceinline__ float rcp_ieee(float x)
+// FAST = true leaves the domain check out: for callers that KNOW 2^-126 <= |x| < 2^126 (the depth keys of a frame
+// whose Sigma^-1 entries are all below 1e36 -- preprocess_kernel reports anything else in the status word and stp_forward
+// then launches the kernels built with the check).  The check is a compare plus a branch per evaluation, and the branch
+// splits the head level's straight-line step into basic blocks: -4 % on the forward without it.
+template <bool FAST = false> __device__ __forceinline__ float rcp_ieee(float x)
 {
     float r = __builtin_amdgcn_rcpf(x);
     r = fmaf(fmaf(-x, r, 1.0f), r, r);
-    const float ax = fabsf(x);
-    if (__builtin_expect(__any(!(ax >= 1.17549435e-38f && ax < 8.5e37f)), 0)) r = 1.0f / x;
+    if constexpr (!FAST) {
+        const float ax = fabsf(x);
+        if (__builtin_expect(__any(!(ax >= 1.17549435e-38f && ax < 8.5e37f)), 0)) r = 1.0f / x;
+    }
     return r;
 }
 
@@ -206,14 +212,14 @@ __device__ __forceinline__ float exp_blend(float x)
 // Depth of the point of maximum contribution along a view ray (reference stopthepop_common.cuh:44-55).
 // p0 = [S00 S01 S02], p1 = [S11 S12 S22], p2 = Sigma^-1 (mu - cam).  Canonical evaluation order:
 // every dot product is fma(c, z, fma(b, y, a*x)); the reciprocal is the IEEE quotient 1/x.
-__device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2, float3 v)
+template <bool FAST = false> __device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2, float3 v)
 {
     const float a0 = fmaf(p0.z, v.z, fmaf(p0.y, v.y, p0.x * v.x));
     const float a1 = fmaf(p1.y, v.z, fmaf(p1.x, v.y, p0.y * v.x));
     const float a2 = fmaf(p1.z, v.z, fmaf(p1.y, v.y, p0.z * v.x));
     const float num = fmaf(p2.z, v.z, fmaf(p2.y, v.y, p2.x * v.x));
     const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
-    const float rcp = rcp_ieee(fmaxf(0.00001f, den));
+    const float rcp = rcp_ieee<FAST>(fmaxf(0.00001f, den));
     return num * rcp;
 }
 
@@ -228,32 +234,32 @@ __device__ __forceinline__ float min_099(float x)
 
 // depth_along_ray() for lane I's packed Sigma^-1 rows (c0 = [S00 S01 S02], c1 = [S11 S12 S22], c2 = Sigma^-1 (mu - cam)),
 // every product taking its broadcast operand through DPP: the same operations in the same order, bit for bit.
-template <int I> __device__ __forceinline__ float depth_along_ray_quad(float4 c0, float4 c1, float4 c2, float3 v)
+template <int I, bool FAST = false> __device__ __forceinline__ float depth_along_ray_quad(float4 c0, float4 c1, float4 c2, float3 v)
 {
     const float a0 = quad_fma<I>(c0.z, v.z, quad_fma<I>(c0.y, v.y, quad_mul<I>(c0.x, v.x)));
     const float a1 = quad_fma<I>(c1.y, v.z, quad_fma<I>(c1.x, v.y, quad_mul<I>(c0.y, v.x)));
     const float a2 = quad_fma<I>(c1.z, v.z, quad_fma<I>(c1.y, v.y, quad_mul<I>(c0.z, v.x)));
     const float num = quad_fma<I>(c2.z, v.z, quad_fma<I>(c2.y, v.y, quad_mul<I>(c2.x, v.x)));
     const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
-    const float rcp = rcp_ieee(fmaxf(0.00001f, den));
+    const float rcp = rcp_ieee<FAST>(fmaxf(0.00001f, den));
     return num * rcp;
 }
 
 // The same for an entry record (BinningState: A = (S00 S01 S02 S11), B = (S12 S22 q.x q.y), C = (q.z . . .)).
-template <int I> __device__ __forceinline__ float depth_along_ray_quad_ent(float4 A, float4 B, float4 C, float3 v)
+template <int I, bool FAST = false> __device__ __forceinline__ float depth_along_ray_quad_ent(float4 A, float4 B, float4 C, float3 v)
 {
     const float a0 = quad_fma<I>(A.z, v.z, quad_fma<I>(A.y, v.y, quad_mul<I>(A.x, v.x)));
     const float a1 = quad_fma<I>(B.x, v.z, quad_fma<I>(A.w, v.y, quad_mul<I>(A.y, v.x)));
     const float a2 = quad_fma<I>(B.y, v.z, quad_fma<I>(B.x, v.y, quad_mul<I>(A.z, v.x)));
     const float num = quad_fma<I>(C.x, v.z, quad_fma<I>(B.w, v.y, quad_mul<I>(B.z, v.x)));
     const float den = fmaf(a2, v.z, fmaf(a1, v.y, a0 * v.x));
-    const float rcp = rcp_ieee(fmaxf(0.00001f, den));
+    const float rcp = rcp_ieee<FAST>(fmaxf(0.00001f, den));
     return num * rcp;
 }
 // depth_along_ray() on an entry record
-__device__ __forceinline__ float depth_along_ray_ent(float4 A, float4 B, float4 C, float3 v)
+template <bool FAST = false> __device__ __forceinline__ float depth_along_ray_ent(float4 A, float4 B, float4 C, float3 v)
 {
-    return depth_along_ray(make_float3(A.x, A.y, A.z), make_float3(A.w, B.x, B.y), make_float3(B.z, B.w, C.x), v);
+    return depth_along_ray<FAST>(make_float3(A.x, A.y, A.z), make_float3(A.w, B.x, B.y), make_float3(B.z, B.w, C.x), v);
 }
 
 __device__ __forceinline__ float3 f4_xyz(float4 a) { return make_float3(a.x, a.y, a.z); }

@@ -125,6 +125,7 @@ struct FrameParams {
     const float* inv_viewprojmatrix;
     const float* cam_pos;
     int prefiltered;
+    int wild_cov; // forward, after the status read-back: some visible Gaussian has a Sigma^-1 entry >= 1e36 or not finite (depth keys then take the reciprocal with its domain check)
 };
 
 struct BackwardParams {

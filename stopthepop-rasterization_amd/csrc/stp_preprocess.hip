@@ -307,6 +307,11 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
         const float ux = (-inv.m[0][0]) * dx + (-inv.m[1][0]) * dy + (-inv.m[2][0]) * dz;
         const float uy = (-inv.m[0][1]) * dx + (-inv.m[1][1]) * dy + (-inv.m[2][1]) * dz;
         const float uz = (-inv.m[0][2]) * dx + (-inv.m[1][2]) * dy + (-inv.m[2][2]) * dz;
+        // (a frame in which this never fires -- every frame of a sane scene -- has depth-key denominators below 9.1e36: its
+        // render kernels take the reciprocal without the domain check, stp_device.h rcp_ieee<true>)
+        const bool tame = fabsf(inv.m[0][0]) < 1.0e36f && fabsf(inv.m[0][1]) < 1.0e36f && fabsf(inv.m[0][2]) < 1.0e36f &&
+                          fabsf(inv.m[1][1]) < 1.0e36f && fabsf(inv.m[1][2]) < 1.0e36f && fabsf(inv.m[2][2]) < 1.0e36f; // (false for NaN)
+        if (!tame) atomicOr(&a.g.status[1], 2u);
         a.g.cov3D_inv[3 * (size_t)idx + 0] = make_float4(inv.m[0][0], inv.m[0][1], inv.m[0][2], 0.0f);
         a.g.cov3D_inv[3 * (size_t)idx + 1] = make_float4(inv.m[1][1], inv.m[1][2], inv.m[2][2], 0.0f);
         a.g.cov3D_inv[3 * (size_t)idx + 2] = make_float4(ux, uy, uz, 0.0f);

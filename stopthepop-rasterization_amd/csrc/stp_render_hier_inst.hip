@@ -38,6 +38,11 @@ hipError_t STP_FN(const FrameParams& f, const RenderArgs& a, hipStream_t st, boo
     const bool cull = f.s.hierarchical_4x4_culling != 0;
     *handled = true;
 #define STP_GO(H) return cull ? launch_hier_one<H, MID, true, MODE>(f, a, st) : launch_hier_one<H, MID, false, MODE>(f, a, st)
+    // the default queue sizes' forward passes also exist without the reciprocal's domain check, for frames whose Sigma^-1
+    // entries are all tame (every frame of a sane scene: FrameParams::wild_cov, from preprocess_kernel's status word)
+    if constexpr (!BWD && MID == 8) {
+        if (head == 4 && !f.wild_cov) return cull ? launch_hier_one<4, MID, true, MODE, true>(f, a, st) : launch_hier_one<4, MID, false, MODE, true>(f, a, st);
+    }
     if (head == 4) STP_GO(4);
 #ifndef STP_FASTBUILD
     if (head == 8) STP_GO(8);

@@ -365,6 +365,34 @@ def test_exact_depth_ties(sd):
     check_against_oracle(sc, sd)
 
 
+@pytest.mark.parametrize("sd", [settings_dict(3), settings_dict(**FULL_STP)], ids=["hier", "full_stp"])
+def test_wild_inverse_covariance_takes_the_checked_reciprocal(sd):
+    """Depth keys are num * (1 / max(1e-5, v' Sigma^-1 v)) with the IEEE quotient (ref: stopthepop_common.cuh:44-55).  The
+    render kernels take it as v_rcp + one Newton step, which is the correctly rounded quotient below 2^126; a frame whose
+    Sigma^-1 entries all stay below 1e36 (every sane frame) runs kernels WITHOUT the domain check, anything else is
+    reported by preprocess_kernel through the status word and runs the kernels with it.  Here: rotations of magnitude
+    4e7..7.4e7 on scales of 1e-17 (which the inverse clamps at 1e-3) in a scene close to the camera -- Sigma^-1 entries of
+    1e37..1.1e38, denominators in the two top binades, everything still finite, the covariance itself ordinary -- must
+    give the oracle's frame bit for bit in its lists and to 2e-6 in its pixels."""
+    sc = scenes.make_scene(P=600, W=112, H=80, sigma_min=1.5, sigma_max=8.0, seed=41, z_range=(0.3, 0.9))
+    wild = np.arange(0, sc.P, 7)
+    mag = np.linspace(4.0e7, 7.4e7, wild.size).astype(np.float32)
+    # keep the visible covariance ordinary: Sigma = (S R)'(S R) grows with |q|^4, so the scales shrink by |q|^2
+    sc.rotations[wild] *= mag[:, None]
+    sc.scales[wild] /= (mag * mag)[:, None]
+    g = GpuRun(sc, sd, backward=False)
+    f, _ = oracle_run(sc, sd, backward=False)
+    assert g.num_rendered == f.num_rendered and g.num_rendered > 0
+    assert np.array_equal(g.radii, f.radii)
+    vis = f.radii > 0
+    inv = g.geom_array("cov3D_inv").reshape(sc.P, -1)[vis]
+    assert np.isfinite(inv).all() and float(np.abs(inv).max()) > 8.5e37  # the scene is what it claims to be
+    assert np.array_equal(g.binning_array("keys"), f.array("keys"))
+    assert np.array_equal(g.binning_array("point_list"), f.array("point_list"))
+    assert not np.isnan(g.color).any()
+    assert max_abs(g.color, f.color) <= 2e-6
+
+
 def test_tile_lists_longer_than_the_lds_sort_capacity():
     """A tile with more than 4096 entries: the tile-local depth sort takes its counting-pass route through the scratch
     arrays (stp_tilesort.hip); keys, list and everything downstream must still match the oracle bit for bit."""
