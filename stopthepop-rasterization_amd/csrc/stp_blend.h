@@ -269,11 +269,12 @@ template <int CAP> struct Window {
                 st = sw[s] ? os : st;
             }
             float nd[CAP];
-            // (min / max as medians with an infinity: one v_med3_f32 each -- fminf / fmaxf cost a canonicalising v_max first)
-            nd[0] = __builtin_amdgcn_fmed3f(-INFINITY, depth[1], c);
+            // (min / max as bare instructions: fminf / fmaxf cost a canonicalising v_max per operand first, and the compiler
+            // folds a median with an infinity back into exactly that -- three instructions where one does)
+            asm("v_min_f32 %0, %1, %2" : "=v"(nd[0]) : "v"(depth[1]), "v"(c));
 #pragma unroll
             for (int s = 1; s < CAP - 1; s++) nd[s] = __builtin_amdgcn_fmed3f(depth[s], depth[s + 1], c);
-            nd[CAP - 1] = __builtin_amdgcn_fmed3f(INFINITY, depth[CAP - 1], c);
+            asm("v_max_f32 %0, %1, %2" : "=v"(nd[CAP - 1]) : "v"(depth[CAP - 1]), "v"(c));
 #pragma unroll
             for (int s = 0; s < CAP; s++) depth[s] = nd[s];
         } else depth[0] = c;
