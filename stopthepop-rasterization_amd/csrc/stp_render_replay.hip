@@ -32,8 +32,9 @@ __device__ unsigned long long g_replay_stats[16];
 namespace {
 
 #ifndef STP_REPLAY_PAIRMERGE
-#define STP_REPLAY_PAIRMERGE 3 // merge levels: 1 = inside 2x2 quads (lane^1, lane^2), 2 = + mirror in the 8-lane half, 3 = + mirror in the 16-lane row
-                               // (C2-full: 1.38 ms without, 0.99 / 0.95 / 0.94 ms with 1 / 2 / 3)
+#define STP_REPLAY_PAIRMERGE 1 // merge levels: 1 = inside 2x2 quads (lane^1, lane^2), 2 = + mirror in the 8-lane half, 3 = + mirror in the 16-lane row
+                               // (C2-full, lanes in step: 1.38 ms without, 0.99 / 0.95 / 0.94 ms with 1 / 2 / 3; de-phased lanes, see
+                               // STP_REPLAY_DEPHASE: 1.01 ms without, 0.92 / 0.95 with 1 / 2)
 #endif
 #ifndef STP_REPLAY_F64
 #define STP_REPLAY_F64 0 // 1: on-chip sums as doubles through ds_add_f64 instead of 64-bit fixed point (one conversion per term instead of
@@ -45,7 +46,10 @@ namespace {
 #ifndef STP_REPLAY_OCC
 #define STP_REPLAY_OCC 4
 #endif
-constexpr int WINDOW = 512;          // list positions per window (9 x 512 x 8 B = 36 KB of LDS: four workgroups per CU)
+#ifndef STP_REPLAY_WINDOW
+#define STP_REPLAY_WINDOW 512
+#endif
+constexpr int WINDOW = STP_REPLAY_WINDOW; // list positions per window (9 x 512 x 8 B = 36 KB of LDS: four workgroups per CU)
 constexpr int EXHAUSTED = 0x7fffffff; // "position" of a lane that has no record left
 
 __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
@@ -160,7 +164,18 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #ifdef STP_REPLAY_STATS
         {
             const int nw = __popcll(__ballot(ok)), ns = __popcll(__ballot(ok && cur_pos < lo));
-            if (lane == 0) { atomicAdd(&g_replay_stats[0], 1ull); atomicAdd(&g_replay_stats[2], (unsigned long long)nw); atomicAdd(&g_replay_stats[3], (unsigned long long)ns); }
+            // lanes whose position a LOWER adding lane also holds (same row / another row): what the LDS serialises
+            bool dup_row = false, dup_any = false;
+            int mult = 1;
+            for (int l = 0; l < 64; l++) {
+                const int pl = __shfl(ok ? cur_pos : -1 - lane, l);
+                if (ok && pl == cur_pos && l != lane) { mult++; if (l < lane) { dup_any = true; if ((l >> 4) == (lane >> 4)) dup_row = true; } }
+            }
+            const int n_dup = __popcll(__ballot(ok && dup_any)), n_dup_row = __popcll(__ballot(ok && dup_row));
+            int mmax = ok ? mult : 0;
+            for (int off = 32; off > 0; off >>= 1) mmax = max(mmax, __shfl_xor(mmax, off));
+            if (lane == 0) { atomicAdd(&g_replay_stats[0], 1ull); atomicAdd(&g_replay_stats[2], (unsigned long long)nw); atomicAdd(&g_replay_stats[3], (unsigned long long)ns);
+                             atomicAdd(&g_replay_stats[4], (unsigned long long)n_dup); atomicAdd(&g_replay_stats[5], (unsigned long long)n_dup_row); atomicAdd(&g_replay_stats[6], (unsigned long long)mmax); }
         }
 #endif
         if (ok) {
@@ -212,6 +227,12 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         }
     };
 
+#ifndef STP_REPLAY_HOIST
+#define STP_REPLAY_HOIST 1
+#endif
+    // (STP_REPLAY_HOIST: the terms of a lane that does not blend in a step are not zeroed -- they keep the lane's last,
+    // finite, values; the merge multiplies such a partner by zero and the lane itself adds nothing)
+    float g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     // Two dependent loads lead to a blend: log record (list position) -> the entry's record.  They are software
     // pipelined one step apart: `pos` / `en` hold the lane's next record and its entry, `pos1` the position of the one
     // after, each loaded an iteration before it is needed.
@@ -220,20 +241,41 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         int nmax = n;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) nmax = max(nmax, __shfl_xor(nmax, off));
-        int pos = (0 < n) ? log_at(0) : -1, pos1 = (1 < n) ? log_at(1) : -1;
+#ifndef STP_REPLAY_DEPHASE
+#define STP_REPLAY_DEPHASE 1
+#endif
+        // De-phasing.  The kernel is bound by the LDS adds, and those by lanes that hit one address in one instruction:
+        // neighbouring pixels blend the same entries in the same order, so lanes that walk their logs in step sit on the
+        // same list position all the time (measured, C2-full, after the four merge levels: 41 adding lanes on 17.5 distinct
+        // positions, the largest group 6 lanes; tools/replay_stats.py).  Lane x of every 16-lane row therefore starts x
+        // iterations late: 15 % more iterations, but 42 adding lanes on 24 positions with the quad merge alone (half the
+        // merge's VALU work), and 0.98 -> 0.92 ms.  (Other patterns measured: by quad 0.96-1.01, by row and lane 1.07, all
+        // 64 lanes apart 1.64 ms.)
+        const int off = STP_REPLAY_DEPHASE == 1 ? x : STP_REPLAY_DEPHASE == 2 ? lane : STP_REPLAY_DEPHASE == 3 ? (x + 4 * s) : STP_REPLAY_DEPHASE == 4 ? 2 * x + (s & 1) : STP_REPLAY_DEPHASE == 5 ? (x >> 2) + 4 * s : STP_REPLAY_DEPHASE == 6 ? 2 * ((x >> 2) + 4 * s) : STP_REPLAY_DEPHASE == 7 ? (x >> 2) : 0;
+        if (STP_REPLAY_DEPHASE) {
+            int nn = n + off;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) nn = max(nn, __shfl_xor(nn, o));
+            nmax = nn;
+        }
+        int kk0 = -off; // my record index in iteration 0
+        int pos = (0 < n && off == 0) ? log_at(0) : -1, pos1 = (1 - off >= 0 && 1 - off < n) ? log_at((uint32_t)(1 - off)) : -1;
         Entry en = entry_at(max(pos, 0));
         for (int k = 0; k < nmax; k++) {
-            const bool have = k < n;
+            const int kr = k - off; // my record index
+            const bool have = kr >= 0 && kr < n;
             const Entry cur = en;
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             // issue the next round of loads before touching this step's data
             en = entry_at(max(pos1, 0));
-            const int pos2 = (k + 2 < n) ? log_at((uint32_t)k + 2) : -1;
+            const int pos2 = (kr + 2 >= 0 && kr + 2 < n) ? log_at((uint32_t)(kr + 2)) : -1;
             pos = pos1;
             pos1 = pos2;
-            float g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#if !STP_REPLAY_HOIST
+            for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
+#endif
             const bool ok = blend_terms(have, cur, g);
-            if (have && !ok) n = k; // (an ulp of difference against the forward's transmittance: stop where it says so)
+            if (have && !ok) n = kr; // (an ulp of difference against the forward's transmittance: stop where it says so)
             merge_and_add(ok, cur_pos, cur_id, g, 0);
         }
         flush_window(0);
@@ -257,7 +299,9 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             pos = act ? pos1 : pos;
             pos1 = act ? (k + 1 < n ? rec : EXHAUSTED) : pos1;
             en = entry_at(pos);
-            float g[9] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+#if !STP_REPLAY_HOIST
+            for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
+#endif
             const bool ok = blend_terms(act, cur, g);
             if (act && !ok) { n = k; pos = EXHAUSTED; pos1 = EXHAUSTED; } // (saturated one record earlier than the forward said)
             merge_and_add(ok, cur_pos, cur_id, g, lo);

@@ -29,3 +29,5 @@ L.stp_debug_replay_stats(out)
 steps, nw, ns = out[0], out[2], out[3]
 print(f"{workload}-{variant}: wave-steps {steps}; per step: lanes that add to LDS after the pairwise merge {nw/steps:.1f}, "
       f"of which stragglers behind their window (global atomics) {ns/steps:.3f}")
+print(f"   of the adding lanes: {out[4]/steps:.1f} hold a position that a lower adding lane holds too ({out[5]/steps:.1f} of them in the same 16-lane row); "
+      f"distinct positions per step {(nw-out[4])/steps:.1f}; largest group on one position {out[6]/steps:.2f}")
