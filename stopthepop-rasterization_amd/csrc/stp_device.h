@@ -332,6 +332,22 @@ __device__ __forceinline__ float max_contrib_power_rect(float4 co, float2 mean, 
     return power;
 }
 
+// Minimum over the rectangle [x0,x1] x [y0,y1] of offsets (pixel - mean) of q(dx,dy) = 0.5 (a dx^2 + c dy^2) + b dx dy,
+// the negated blend exponent (co = (a, b, c, opacity)).  q is convex for a positive definite conic: the minimum is 0 when
+// the mean lies inside, otherwise it is on the boundary -- on each of the four edges a one-dimensional parabola whose
+// vertex is clamped to the edge.  Anything unexpected (a or c not positive, NaN) returns 0, i.e. "may contribute".
+__device__ __forceinline__ float min_power_rect(float4 co, float x0, float x1, float y0, float y1)
+{
+    const float A = co.x, B = co.y, C = co.z;
+    if (!(A > 0.0f && C > 0.0f)) return 0.0f;
+    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return 0.0f;
+    auto q = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
+    auto on_x_edge = [&](float X) { return q(X, fminf(fmaxf(-B * X / C, y0), y1)); }; // dx = X fixed, dy free in [y0, y1]
+    auto on_y_edge = [&](float Y) { return q(fminf(fmaxf(-B * Y / A, x0), x1), Y); };
+    const float m = fminf(fminf(on_x_edge(x0), on_x_edge(x1)), fminf(on_y_edge(y0), on_y_edge(y1)));
+    return m == m ? fmaxf(m, 0.0f) : 0.0f;
+}
+
 __device__ __forceinline__ uint64_t make_sort_key(uint32_t tile, float depth) // reference auxiliary.h:238-244
 {
     return ((uint64_t)tile << 32) | (uint64_t)__float_as_uint(depth);

@@ -1,0 +1,303 @@
+// stp_render_kbuf.hip -- PPX_KBUFFER forward passes (plain, recording, depth visualisation) on the wave64 machinery of the
+// hierarchical kernel's head level.
+//
+// Replaces renderkBufferCUDA<3, W, false> (reference stopthepop/resorted_render.cuh:17-221): per pixel a sorted window of W
+// entries keyed by the depth along the pixel's own ray; every entry of the tile's list is looked at in list order -- "if the
+// window is full, blend its front; then, if the entry passes the tests, insert it" -- and the window is drained at the end.
+//
+// What the result depends on, and what it does not (the same argument as stp_render_hier.inc, filter_push): an entry that
+// FAILS the tests can only cost the pixel a pop of the window's front -- which the next passing entry would have popped
+// anyway before being inserted, and which a second failing entry no longer finds.  The sequence of blended entries is
+// therefore the same whichever of the failing entries a pixel is shown, and a pixel's work is "its passing entries, in list
+// order".  The previous kernel (stp_render_tile.hip, still the re-sorting BACKWARD and the large windows) walked the whole
+// list with all 64 lanes of a wave on the same entry: 600 cycles for every entry that reached any of the wave's 64 pixels,
+// a third of the lanes doing anything.  Here:
+//
+//   * thread -> pixel as in the hierarchical and replay kernels (wave = row of four 4x4 sub-tiles, sub-tile = 16-lane DPP
+//     row, 2x2 quad = DPP quad), so the recording forward writes the same blend log and the replay kernel is its backward;
+//   * a batch of 32 list entries is tested against the wave's four sub-tiles by the 64 lanes together (lane = entry x pair of
+//     sub-tiles): the EXACT minimum of the exponent's quadratic form over the sub-tile's rectangle, with a margin that
+//     covers every rounding of the per-pixel evaluation -- a bound, unlike the reference's max-contribution estimate;
+//     survivors are compacted per sub-tile with ballots, in list order;
+//   * each quad tests a sub-tile's survivors against its own four pixels (lane q takes survivor 4g + q; quad_can_blend) and
+//     parks what is left in its FIFO; head steps then run on groups of four parked entries with every quad of the wave on
+//     its OWN entries -- the step itself (entry record fetched by one lane of the quad, DPP-operand evaluation, always-full
+//     window with fused pop + insert) is the hierarchical head level's with HEAD = W.
+//
+// n_contrib: the reference counts the entries a pixel looked at before it saturated.  A pop that saturates is either the
+// pop in front of the entry that follows the insertion which filled the window (count = that insertion's position + 1) or a
+// pop of the final drain (count = the whole list); both are known here without having looked at the entries in between.
+#include "stp_internal.h"
+#include "stp_blend.h"
+
+namespace stp {
+
+namespace {
+
+constexpr int KB_CAP = 32; // list positions a quad's FIFO may hold (one round of 16 survivors adds up to 16)
+
+__device__ __forceinline__ int kb_remap_tile(int wg, int n_wg)
+{
+    const int q = n_wg >> 3, r = n_wg & 7;
+    const int xcd = wg & 7, k = wg >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+constexpr int KBW_FWD = 0, KBW_RECORD = 2, KBW_DEPTH = 3; // (the values of the hierarchical kernel's modes)
+
+template <int WIN> constexpr int kb_waves() { return WIN <= 4 ? 4 : 3; } // waves per SIMD the kernel is compiled for
+
+template <int WIN, int MODE, bool FRCP>
+__global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kernel(const RenderArgs a)
+{
+    constexpr bool RECORD = MODE == KBW_RECORD;
+    constexpr bool DEPTHVIZ = MODE == KBW_DEPTH;
+    __shared__ int s_stage[16 * 32];      // [sub-tile][survivor]: list positions of the staged batch, per sub-tile
+    __shared__ int s_fifo[64 * KB_CAP];   // [quad][slot]
+
+    const int lane = (int)(threadIdx.x & 63);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
+    const int rows = a.ty1 - a.ty0;
+    const int t = kb_remap_tile((int)blockIdx.x, a.gx * rows);
+    const int tile_x = t % a.gx, tile_y = a.ty0 + t / a.gx, tile = tile_y * a.gx + tile_x;
+    const uint2 range = a.ranges[tile];
+    const int total = (int)(range.y - range.x);
+    const int cx = tile_x * TILE + 4 * s, cy = tile_y * TILE + 4 * w;
+    const int px = cx + 2 * (m & 1) + (q & 1), py = cy + 2 * (m >> 1) + (q >> 1);
+    const bool inside = px < a.W && py < a.H;
+    bool active = inside;
+
+    const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
+    const float3 pix_dir = view_ray(a.inv_vp, cam, (float)px, (float)py, a.W, a.H);
+
+    const float4* const eA = a.entA + range.x;
+    const float4* const eB = a.entB + range.x;
+    const float4* const eC = a.entC + range.x;
+    const float4* const eD = a.entD + range.x;
+    const float4* const eF = a.entF + range.x;
+    const int list_last = max(total - 1, 0);
+    auto ent_row = [&](const float4* base, int pos) __attribute__((always_inline)) -> float4 { // SGPR base + 32-bit offset
+        return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4));
+    };
+
+    // blend log (recording forward): as in stp_render_hier.inc
+    char* const log_wave = RECORD ? reinterpret_cast<char*>(a.blend_log) + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 * sizeof(log_t) : nullptr;
+    constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
+    uint32_t log_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
+    auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
+        if (upd && log_off < BLEND_LOG_DEPTH * LOG_ROW) *reinterpret_cast<log_t*>(log_wave + log_off) = (log_t)pay;
+        log_off += upd ? LOG_ROW : 0u;
+    };
+
+    Window<WIN> head;
+    head.init_padded();
+    FwdPixel fp;
+    init_fwd_pixel(fp);
+    float depth_acc = 0.0f;
+    int contrib = total; // n_contrib of the plain / depth forward (see the header)
+    int cfull = total;   // what it becomes if the NEXT pop saturates the pixel
+
+    // The window does not carry alpha (W registers and W selects per step): it is evaluated again at the pop, from the same
+    // record with the same operations, hence to the same bits as when the entry passed its tests.  What the pop needs of
+    // the front entry -- mean, conic + opacity, colour -- is fetched when the entry BECOMES the front, one step earlier.
+    float4 frC = make_float4(0, 0, 0, 0), frD = frC, frF = frC;
+    auto fetch_front = [&]() __attribute__((always_inline)) {
+        const int nx = head.id[0]; // (a pad carries position 0: a harmless read)
+        frC = ent_row(eC, nx); frD = ent_row(eD, nx); frF = ent_row(eF, nx);
+    };
+    auto pop_forward = [&]() __attribute__((always_inline)) { // consumes slot 0 of the always-full window; replace_front() follows
+        const float alpha0 = fminf(0.99f, frD.w * exp_blend(blend_power(frC.y - (float)px, frC.z - (float)py, frD)));
+        const float test_T = fp.T * (1.0f - alpha0);
+        const bool doing = active && !(head.depth[0] < 0.0f); // a pad in front = the reference's window is not full: nothing to blend
+        const bool upd = doing && !(test_T < T_THRESHOLD);
+        const int pay = head.id[0];
+        const float wgt = upd ? alpha0 * fp.T : 0.0f;
+        fp.C[0] = fmaf(wgt, frF.x, fp.C[0]); fp.C[1] = fmaf(wgt, frF.y, fp.C[1]); fp.C[2] = fmaf(wgt, frF.z, fp.C[2]);
+        if constexpr (DEPTHVIZ) depth_acc += upd ? head.depth[0] * alpha0 * fp.T : 0.0f; // reference resorted_render.cuh:107
+        fp.T = upd ? test_T : fp.T;
+        if constexpr (RECORD) log_append(upd, pay);
+        else contrib = (doing && !upd) ? cfull : contrib;
+        active = active && (upd || !doing);
+    };
+
+    // four candidates per quad, lane q brings candidate q (list position, -1 = none): the hierarchical head level's step
+    auto feed4_from = [&](const int fid) __attribute__((always_inline)) {
+        const int pf = min(max(fid, 0), list_last);
+        float4 eAq = ent_row(eA, pf), eBq = ent_row(eB, pf), eCq = ent_row(eC, pf), eDq = ent_row(eD, pf);
+#define STP_KB_FEED(I)                                                                                                  \
+    {                                                                                                                   \
+        pop_forward();                                                                                                  \
+        const int cid = quad_bcast_i<I>(pf);                                                                            \
+        if constexpr (I == 0) {                                                                                         \
+            eDq.w = fid < 0 ? 0.0f : eDq.w; /* no candidate: alpha 0 fails the tests */                                 \
+            dpp_hazard_guard_on(eDq.w);                                                                                 \
+        } else dpp_hazard_guard();                                                                                      \
+        const float depth = depth_along_ray_quad_ent<I, FRCP>(eAq, eBq, eCq, pix_dir);                                  \
+        const float dx = quad_sub<I>(eCq.y, (float)px), dy = quad_sub<I>(eCq.z, (float)py);                             \
+        const float power = blend_power_quad<I>(dx, dy, eDq);                                                           \
+        const float alpha = min_099(quad_mul<I>(eDq.w, exp_blend(power)));                                              \
+        const bool pass = active && !(depth < 0.0f) && !(power > 0.0f) && !(alpha < ALPHA_THRESHOLD);                   \
+        head.replace_front(pass, pass ? depth : -FLT_MAX, cid, 0.0f);                                                   \
+        fetch_front();                                                                                                  \
+        if constexpr (!RECORD) cfull = pass ? cid + 1 : cfull;                                                          \
+    }
+        STP_KB_FEED(0) STP_KB_FEED(1) STP_KB_FEED(2) STP_KB_FEED(3)
+#undef STP_KB_FEED
+    };
+
+    // can the entry reach 1/255 at any of the quad's four pixels?  (stp_render_hier.inc quad_can_blend: an upper bound of
+    // opacity * exp(power) over the four pixels that covers every rounding of the per-pixel evaluation)
+    auto quad_can_blend = [&](const float4 C, const float4 D, const float qx0, const float qy0) __attribute__((always_inline)) -> bool {
+        const float dx0 = C.y - qx0, dx1 = C.y - (qx0 + 1.0f), dy0 = C.z - qy0, dy1 = C.z - (qy0 + 1.0f);
+        const float ax0 = D.x * dx0 * dx0, ax1 = D.x * dx1 * dx1, cy0 = D.z * dy0 * dy0, cy1 = D.z * dy1 * dy1;
+        const float b0 = D.y * dx0, b1 = D.y * dx1;
+        const float q00 = fmaf(b0, dy0, 0.5f * (ax0 + cy0)), q01 = fmaf(b0, dy1, 0.5f * (ax0 + cy1));
+        const float q10 = fmaf(b1, dy0, 0.5f * (ax1 + cy0)), q11 = fmaf(b1, dy1, 0.5f * (ax1 + cy1));
+        const float qmin = fminf(fminf(q00, q01), fminf(q10, q11));
+        const float mx = fmaxf(fmaxf(fabsf(dx0), fabsf(dx1)), fmaxf(fabsf(dy0), fabsf(dy1)));
+        const float S = (fabsf(D.x) + fabsf(D.z) + fabsf(D.y)) * mx * mx;
+        const float pup = fmaf(S, 2.0e-6f, -qmin);
+        const float v = D.w * __builtin_amdgcn_exp2f(pup * 1.44269502162933349609375f);
+        return !(v < ALPHA_THRESHOLD * 0.9999f); // NaN: kept, the exact test decides
+    };
+
+    int* const hfifo = s_fifo + ((w * 4 + s) * 4 + m) * KB_CAP;
+    int hf_head = 0, hf_cnt = 0; // (quad-uniform)
+    auto head_round = [&](const bool force) __attribute__((always_inline)) -> bool { // false: nothing (more) to do now
+        const unsigned long long act = __ballot(active);
+        const bool qlive = ((act >> (lane & ~3)) & 0xFull) != 0ull;
+        if (!qlive) { hf_head = (hf_head + hf_cnt) & (KB_CAP - 1); hf_cnt = 0; } // nobody left to show them to
+        bool go;
+        if (force) go = __any(hf_cnt > 0);
+        else go = __any(hf_cnt > KB_CAP - 16) || (__all(hf_cnt >= 4 || !qlive) && __any(hf_cnt >= 4));
+        if (!go) return false;
+        const int n = min(hf_cnt, 4);
+        wave_sync();
+        const int fid = q < n ? hfifo[(hf_head + q) & (KB_CAP - 1)] : -1;
+        hf_head = (hf_head + n) & (KB_CAP - 1);
+        hf_cnt -= n;
+        feed4_from(fid);
+        return true;
+    };
+    auto head_rounds = [&](const bool force) __attribute__((always_inline)) {
+#pragma unroll 1
+        for (;;) {
+            if (!head_round(force)) break;
+            if constexpr (WIN <= 8) { if (!head_round(force)) break; } // (two copies of the group step: fewer register shuffles per step)
+        }
+    };
+
+    // ---- main loop: batches of 32 list entries -----------------------------------------------------------------------
+    const int half = lane >> 5, e = lane & 31;
+    const float sxA = (float)(tile_x * TILE + 8 * half), sxB = sxA + 4.0f, syf = (float)cy;
+    int* const stA = s_stage + (w * 4 + 2 * half) * 32; // my half's two sub-tiles: [0..32) and [32..64)
+    const int* const st_row = s_stage + (w * 4 + s) * 32;
+    const float qx0 = (float)(px - (q & 1)), qy0 = (float)(py - (q >> 1));
+#pragma unroll 1
+    for (int base = 0; base < total; base += 32) {
+        if (!__any(active)) break;
+        // stage: lane = entry e of the batch x the sub-tile pair of my half
+        const int ep = base + e;
+        bool keepA = false, keepB = false;
+        if (ep < total) {
+            const float4 C = ent_row(eC, ep), D = ent_row(eD, ep);
+            const float x0A = sxA - C.y, x0B = sxB - C.y, y0 = syf - C.z;
+            const float pA = min_power_rect(D, x0A, x0A + 3.0f, y0, y0 + 3.0f);
+            const float pB = min_power_rect(D, x0B, x0B + 3.0f, y0, y0 + 3.0f);
+            // rounding of the per-pixel exponent against this one: at most a few ulp of the form's terms, all below T * far^2
+            const float T3 = fabsf(D.x) + fabsf(D.y) + fabsf(D.z);
+            const float fy = fmaxf(fabsf(y0), fabsf(y0 + 3.0f));
+            const float fA = fmaxf(fmaxf(fabsf(x0A), fabsf(x0A + 3.0f)), fy), fB = fmaxf(fmaxf(fabsf(x0B), fabsf(x0B + 3.0f)), fy);
+            keepA = !(D.w * __builtin_amdgcn_exp2f(fmaf(T3 * fA * fA, 2.0e-6f, -pA) * 1.44269502162933349609375f) < ALPHA_THRESHOLD * 0.9999f);
+            keepB = !(D.w * __builtin_amdgcn_exp2f(fmaf(T3 * fB * fB, 2.0e-6f, -pB) * 1.44269502162933349609375f) < ALPHA_THRESHOLD * 0.9999f);
+        }
+        const unsigned long long balA = __ballot(keepA), balB = __ballot(keepB);
+        const unsigned int mA = (unsigned int)(balA >> (32 * half)), mB = (unsigned int)(balB >> (32 * half));
+        const unsigned int below = (1u << e) - 1u;
+        wave_sync(); // (the previous batch's readers are done)
+        if (keepA) stA[__popc(mA & below)] = ep;
+        if (keepB) stA[32 + __popc(mB & below)] = ep;
+        wave_sync();
+        const int n_s = __popc((unsigned int)(((s & 1) ? balB : balA) >> (32 * (s >> 1)))); // my sub-tile's survivors
+        // feed: groups of four survivors per quad, head steps after every 16
+        int n_max = n_s;
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) n_max = max(n_max, __shfl_xor(n_max, o));
+#pragma unroll 1
+        for (int g0 = 0; g0 < n_max; g0 += 16) {
+#pragma unroll 1
+            for (int g = g0; g < min(g0 + 16, n_max); g += 4) {
+                const int i = g + q;
+                int fid = -1;
+                if (i < n_s) fid = st_row[i];
+                bool keep = false;
+                const unsigned long long act = __ballot(active);
+                const bool qlive = ((act >> (lane & ~3)) & 0xFull) != 0ull;
+                if (fid >= 0 && qlive) keep = quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qx0, qy0);
+                int bits = keep ? (1 << q) : 0;
+                bits += __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
+                bits += __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
+                if (keep) hfifo[(hf_head + hf_cnt + __popc(bits & ((1 << q) - 1))) & (KB_CAP - 1)] = fid;
+                hf_cnt += __popc(bits);
+            }
+            head_rounds(false);
+        }
+    }
+    head_rounds(true);
+    // drain: fillers that sort LAST push the remaining real entries to the front, one per step
+#pragma unroll 1
+    for (int it = 0; it < WIN; it++) {
+        pop_forward();
+        head.replace_front(false, FLT_MAX, 0, 0.0f);
+        fetch_front();
+        cfull = total; // (only the drain's first pop can be the one "in front of the next entry")
+    }
+
+    if (inside) {
+        const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
+        a.final_T[pid] = fp.T;
+        a.n_contrib[pid] = RECORD ? (uint32_t)(log_off / LOG_ROW) : (uint32_t)contrib; // (recording forward: the pixel's number of log records)
+        if constexpr (DEPTHVIZ) {
+            a.out_color[pid] = depth_acc;
+            a.out_color[N + pid] = fp.T;
+        } else {
+            a.out_color[pid] = fp.C[0] + fp.T * a.bg[0];
+            a.out_color[N + pid] = fp.C[1] + fp.T * a.bg[1];
+            a.out_color[2 * N + pid] = fp.C[2] + fp.T * a.bg[2];
+        }
+    }
+    if constexpr (RECORD) {
+        if ((int)(log_off / LOG_ROW) > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u; // log overflow: this tile's backward re-sorts
+    }
+}
+
+template <int WIN, int MODE> hipError_t launch_kb_win(const FrameParams& f, const RenderArgs& a, hipStream_t st)
+{
+    const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(256);
+    if (f.wild_cov) hipLaunchKernelGGL((render_kbuffer_wave_kernel<WIN, MODE, false>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((render_kbuffer_wave_kernel<WIN, MODE, true>), grid, block, 0, st, a);
+    return hipGetLastError();
+}
+
+} // namespace
+
+// mode: 0 forward, 2 recording forward, 3 depth visualisation.  *handled = false: this window size stays with the kernel of
+// stp_render_tile.hip (windows above 16 entries: the window would not fit the register file next to the head step)
+hipError_t launch_kbuffer_wave(int mode, const FrameParams& f, const RenderArgs& a, hipStream_t st, bool* handled)
+{
+    const int w = f.s.queue_per_pixel; // reference forward.cu:409-425: the next supported window
+    *handled = true;
+#define STP_KBW(WIN) return mode == KBW_RECORD ? launch_kb_win<WIN, KBW_RECORD>(f, a, st) : mode == KBW_DEPTH ? launch_kb_win<WIN, KBW_DEPTH>(f, a, st) : launch_kb_win<WIN, KBW_FWD>(f, a, st)
+    if (w <= 1) STP_KBW(1);
+    if (w <= 2) STP_KBW(2);
+    if (w <= 4) STP_KBW(4);
+    if (w <= 8) STP_KBW(8);
+    if (w <= 12) STP_KBW(12);
+    if (w <= 16) STP_KBW(16);
+#undef STP_KBW
+    *handled = false;
+    return hipSuccess;
+}
+
+} // namespace stp

@@ -13,6 +13,8 @@
 // In GLOBAL backward all 64 lanes of a wave hold the SAME Gaussian at every step, so the nine
 // gradient terms are reduced across the wave with DPP and leave as nine atomics per wave instead
 // of 9 x 64.
+#include <cstdlib>
+#include <cstring>
 #include "stp_internal.h"
 #include "stp_blend.h"
 
@@ -247,21 +249,7 @@ __global__ void __launch_bounds__(BLOCK) render_global_bwd_kernel(const RenderAr
 // ------------------------------------------------------------------------------------------------
 // PPX_KBUFFER forward / backward: per-pixel sorted window keyed by depth along the pixel's own ray
 // ------------------------------------------------------------------------------------------------
-// Minimum over the rectangle [x0,x1] x [y0,y1] of offsets (pixel - mean) of q(dx,dy) = 0.5 (a dx^2 + c dy^2) + b dx dy,
-// the negated blend exponent (co = (a, b, c, opacity)).  q is convex for a positive definite conic: the minimum is 0 when
-// the mean lies inside, otherwise it is on the boundary -- on each of the four edges a one-dimensional parabola whose
-// vertex is clamped to the edge.  Anything unexpected (a or c not positive, NaN) returns 0, i.e. "may contribute".
-__device__ __forceinline__ float min_power_rect(float4 co, float x0, float x1, float y0, float y1)
-{
-    const float A = co.x, B = co.y, C = co.z;
-    if (!(A > 0.0f && C > 0.0f)) return 0.0f;
-    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return 0.0f;
-    auto q = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
-    auto on_x_edge = [&](float X) { return q(X, fminf(fmaxf(-B * X / C, y0), y1)); }; // dx = X fixed, dy free in [y0, y1]
-    auto on_y_edge = [&](float Y) { return q(fminf(fmaxf(-B * Y / A, x0), x1), Y); };
-    const float m = fminf(fminf(on_x_edge(x0), on_x_edge(x1)), fminf(on_y_edge(y0), on_y_edge(y1)));
-    return m == m ? fmaxf(m, 0.0f) : 0.0f;
-}
+// (min_power_rect: stp_device.h)
 
 // MODE 0 = forward, 1 = backward that re-runs the window sort (the reference's scheme; nine atomics per blended pair),
 // 2 = training forward: additionally records every pixel's blend order in the blend log, so that the backward is the
@@ -436,6 +424,7 @@ hipError_t launch_hier_dbg(const FrameParams& f, const RenderArgs& a, hipStream_
 hipError_t launch_depth_colormap(float* out_color, int N, uint32_t* minmax, hipStream_t st); // stp_debug_viz.hip
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st);
 hipError_t launch_full_fwd(const FrameParams& f, const RenderArgs& a, hipStream_t st);
+hipError_t launch_kbuffer_wave(int mode, const FrameParams& f, const RenderArgs& a, hipStream_t st, bool* handled); // stp_render_kbuf.hip
 
 template <int MODE> static hipError_t launch_kbuffer(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {
@@ -465,9 +454,19 @@ hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, c
     case MODE_GLOBAL:
         hipLaunchKernelGGL(render_global_fwd_kernel, grid, block, 0, st, a);
         return hipGetLastError();
-    case MODE_KBUFFER:
+    case MODE_KBUFFER: {
+        // windows up to 16 entries: the wave64 kernel of stp_render_kbuf.hip (STP_KBUFFER=tile keeps the one-entry-per-wave
+        // kernel of this file for comparison; the results are the same)
+        static const char* const kb_env = std::getenv("STP_KBUFFER");
+        static const bool kb_tile = kb_env && std::strcmp(kb_env, "tile") == 0;
+        if (!kb_tile) {
+            bool handled = false;
+            const hipError_t e = launch_kbuffer_wave(a.debug_depth ? KB_FWD_DEPTH : uses_blend_log(f.s) ? KB_FWD_RECORD : KB_FWD, f, a, st, &handled);
+            if (handled) return e;
+        }
         if (a.debug_depth) return launch_kbuffer<KB_FWD_DEPTH>(f, a, st);
         return uses_blend_log(f.s) ? launch_kbuffer<KB_FWD_RECORD>(f, a, st) : launch_kbuffer<KB_FWD>(f, a, st);
+    }
     case MODE_FULL: return launch_full_fwd(f, a, st);
     case MODE_HIER:
         if (a.debug_depth) return launch_hier_dbg(f, a, st, err);
