@@ -132,7 +132,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         return ok;
     };
     // merge lanes on the same position, then add to the window's sums (lo = first position of the window)
-    auto merge_and_add = [&](bool ok, int cur_pos, int cur_id, float (&g)[9], int lo) __attribute__((always_inline)) {
+    // deep (wave-uniform): also the two mirror levels inside the 16-lane row
+    auto merge_and_add = [&](bool ok, int cur_pos, int cur_id, float (&g)[9], int lo, const bool deep) __attribute__((always_inline)) {
 #if STP_REPLAY_PAIRMERGE
         // Pairwise merge (DPP): a lane and its partner -- lane^1, lane^2, then the mirror lanes of its 8-lane half and
         // row -- that hold the same list position sum their terms in registers and only one of them goes to LDS.  Per
@@ -152,12 +153,10 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             }
             STP_MERGE_LEVEL(0xB1, (q & 1) == 0) // partner lane ^ 1 (quad_perm [1,0,3,2])
             STP_MERGE_LEVEL(0x4E, (q & 2) == 0) // partner lane ^ 2 (quad_perm [2,3,0,1])
-#if STP_REPLAY_PAIRMERGE >= 2
-            STP_MERGE_LEVEL(0x141, (x & 7) < 4)  // partner 7 - i inside each 8-lane half (row_half_mirror)
-#endif
-#if STP_REPLAY_PAIRMERGE >= 3
-            STP_MERGE_LEVEL(0x140, x < 8)        // partner 15 - i inside the 16-lane row (row_mirror)
-#endif
+            if (deep) {
+                STP_MERGE_LEVEL(0x141, (x & 7) < 4)  // partner 7 - i inside each 8-lane half (row_half_mirror)
+                STP_MERGE_LEVEL(0x140, x < 8)        // partner 15 - i inside the 16-lane row (row_mirror)
+            }
 #undef STP_MERGE_LEVEL
         }
 #endif
@@ -227,6 +226,17 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         }
     };
 
+    // Where the splats are larger than the wave's 16x4 pixels every lane blends the same entries whatever its phase: de-phasing
+    // buys nothing there and the two mirror levels of the merge are what keeps the LDS adds apart (workload L1: 2.8 ms with
+    // them, 3.1 ms without).  Decided once per wave: do most of its pixels START on the same entry?
+    bool same_start;
+    {
+        const int p0 = n > 0 ? log_at(0) : 0x7fffffff;
+        int pmin = p0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) pmin = min(pmin, __shfl_xor(pmin, o));
+        same_start = __popcll(__ballot(p0 == pmin && n > 0)) >= 40;
+    }
 #ifndef STP_REPLAY_HOIST
 #define STP_REPLAY_HOIST 1
 #endif
@@ -251,7 +261,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         // iterations late: 15 % more iterations, but 42 adding lanes on 24 positions with the quad merge alone (half the
         // merge's VALU work), and 0.98 -> 0.92 ms.  (Other patterns measured: by quad 0.96-1.01, by row and lane 1.07, all
         // 64 lanes apart 1.64 ms.)
-        const int off = STP_REPLAY_DEPHASE == 1 ? x : STP_REPLAY_DEPHASE == 2 ? lane : STP_REPLAY_DEPHASE == 3 ? (x + 4 * s) : STP_REPLAY_DEPHASE == 4 ? 2 * x + (s & 1) : STP_REPLAY_DEPHASE == 5 ? (x >> 2) + 4 * s : STP_REPLAY_DEPHASE == 6 ? 2 * ((x >> 2) + 4 * s) : STP_REPLAY_DEPHASE == 7 ? (x >> 2) : 0;
+        const bool dense = STP_REPLAY_DEPHASE == 0 || same_start; // (wave-uniform)
+        const int off = dense ? 0 : x;
         if (STP_REPLAY_DEPHASE) {
             int nn = n + off;
 #pragma unroll
@@ -276,7 +287,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #endif
             const bool ok = blend_terms(have, cur, g);
             if (have && !ok) n = kr; // (an ulp of difference against the forward's transmittance: stop where it says so)
-            merge_and_add(ok, cur_pos, cur_id, g, 0);
+            merge_and_add(ok, cur_pos, cur_id, g, 0, dense);
         }
         flush_window(0);
     } else {
@@ -304,7 +315,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #endif
             const bool ok = blend_terms(act, cur, g);
             if (act && !ok) { n = k; pos = EXHAUSTED; pos1 = EXHAUSTED; } // (saturated one record earlier than the forward said)
-            merge_and_add(ok, cur_pos, cur_id, g, lo);
+            merge_and_add(ok, cur_pos, cur_id, g, lo, same_start);
         }
         flush_window(lo);
         if (win + 1 < n_win) __syncthreads();
