@@ -119,6 +119,22 @@ def test_kbuffer_windows(window):
     check_against_oracle(scenes.make_scene(P=3000, W=80, H=64, sigma_min=2.0, sigma_max=12.0, seed=5), settings_dict(2, per_pixel=window))
 
 
+@pytest.mark.parametrize("mode,window", [(0, 4), (2, 1), (2, 4), (2, 8), (2, 12), (2, 16), (2, 24)])
+def test_n_contrib_of_the_plain_forward(mode, window):
+    """n_contrib of a forward that records no blend log (inference): GLOBAL = the last contributing list entry + 1
+    (ref: forward.cu:352-361), PPX_KBUFFER = the entries a pixel looked at before it saturated (ref: resorted_render.cuh:
+    17-221) -- which the wave64 k-buffer kernel does not count but derives from the insertion that filled the window
+    (stp_render_kbuf.hip).  Dense scene: most pixels saturate, inside the list and in the final drain."""
+    sc = scenes.make_scene(**DENSE)
+    sd = settings_dict(mode, per_pixel=window)
+    g = GpuRun(sc, sd, backward=False)
+    f, _ = oracle_run(sc, sd, backward=False)
+    a, b = g.image_array("n_contrib").view(np.uint32).reshape(-1)[:sc.W * sc.H], f.array("n_contrib").reshape(-1)
+    assert (b < b.max()).any() and (b == b.max()).any()  # both kinds of pixel occur
+    assert np.array_equal(a, b)
+    assert max_abs(g.color, f.color) <= 2e-6
+
+
 def test_ppx_full_forward_and_no_backward():
     sc = scenes.make_scene(P=2500, W=48, H=32, sigma_min=2.0, sigma_max=12.0, seed=5, camera="orbit")  # > 1024 per tile
     check_against_oracle(sc, settings_dict(1), backward=False)
