@@ -148,16 +148,15 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
 
     // can the entry reach 1/255 at any of the quad's four pixels?  (stp_render_hier.inc quad_can_blend: an upper bound of
     // opacity * exp(power) over the four pixels that covers every rounding of the per-pixel evaluation)
-    auto quad_can_blend = [&](const float4 C, const float4 D, const float qx0, const float qy0) __attribute__((always_inline)) -> bool {
-        const float dx0 = C.y - qx0, dx1 = C.y - (qx0 + 1.0f), dy0 = C.z - qy0, dy1 = C.z - (qy0 + 1.0f);
-        const float ax0 = D.x * dx0 * dx0, ax1 = D.x * dx1 * dx1, cy0 = D.z * dy0 * dy0, cy1 = D.z * dy1 * dy1;
-        const float b0 = D.y * dx0, b1 = D.y * dx1;
-        const float q00 = fmaf(b0, dy0, 0.5f * (ax0 + cy0)), q01 = fmaf(b0, dy1, 0.5f * (ax0 + cy1));
-        const float q10 = fmaf(b1, dy0, 0.5f * (ax1 + cy0)), q11 = fmaf(b1, dy1, 0.5f * (ax1 + cy1));
-        const float qmin = fminf(fminf(q00, q01), fminf(q10, q11));
-        const float mx = fmaxf(fmaxf(fabsf(dx0), fabsf(dx1)), fmaxf(fabsf(dy0), fabsf(dy1)));
-        const float S = (fabsf(D.x) + fabsf(D.z) + fabsf(D.y)) * mx * mx;
-        const float pup = fmaf(S, 2.0e-6f, -qmin);
+    auto quad_can_blend = [&](const float4 C, const float4 D, const float qxc, const float qyc) __attribute__((always_inline)) -> bool { // (qxc, qyc): the quad's centre
+        const float dx = C.y - qxc, dy = C.z - qyc;
+        const float gx = fmaf(D.y, dy, D.x * dx), gy = fmaf(D.z, dy, D.y * dx);
+        const float q2 = fmaf(gy, dy, gx * dx);
+        const float m2 = fminf(fmaf(D.y, 0.5f, -fabsf(gx + gy)), fmaf(D.y, -0.5f, -fabsf(gx - gy)));
+        const float qmin2 = fmaf(D.x + D.z, 0.25f, q2) + m2; // 2 x the smallest negated exponent among the four pixels
+        const float far = fmaxf(fabsf(dx), fabsf(dy)) + 0.5f;
+        const float S = (fabsf(D.x) + fabsf(D.z) + fabsf(D.y)) * far * far;
+        const float pup = fmaf(qmin2, -0.5f, S * 2.0e-6f);
         const float v = D.w * __builtin_amdgcn_exp2f(pup * 1.44269502162933349609375f);
         return !(v < ALPHA_THRESHOLD * 0.9999f); // NaN: kept, the exact test decides
     };
@@ -193,7 +192,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     const float sxA = (float)(tile_x * TILE + 8 * half), sxB = sxA + 4.0f, syf = (float)cy;
     int* const stA = s_stage + (w * 4 + 2 * half) * 32; // my half's two sub-tiles: [0..32) and [32..64)
     const int* const st_row = s_stage + (w * 4 + s) * 32;
-    const float qx0 = (float)(px - (q & 1)), qy0 = (float)(py - (q >> 1));
+    const float qxc = (float)(px - (q & 1)) + 0.5f, qyc = (float)(py - (q >> 1)) + 0.5f; // centre of my 2x2 quad
 #pragma unroll 1
     for (int base = 0; base < total; base += 32) {
         if (!__any(active)) break;
@@ -234,7 +233,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
                 bool keep = false;
                 const unsigned long long act = __ballot(active);
                 const bool qlive = ((act >> (lane & ~3)) & 0xFull) != 0ull;
-                if (fid >= 0 && qlive) keep = quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qx0, qy0);
+                if (fid >= 0 && qlive) keep = quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qxc, qyc);
                 int bits = keep ? (1 << q) : 0;
                 bits += __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
                 bits += __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
