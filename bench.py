@@ -302,11 +302,16 @@ def main():
         dom_ms = stage_ms.get(dom, float("nan"))
         achieved = alg[dom_key] / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
         if mode == 3:
-            kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1>") if dom == "BwdRender" \
-                else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}>"
+            # (last template argument: the depth keys' reciprocal without its domain check -- the default queue sizes'
+            # forward passes on a frame whose Sigma^-1 is tame, which every synthetic workload is)
+            frcp = "true" if (head == 4 and mid == 8) else "false"
+            kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
+                else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
         elif mode == 2:
+            win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
             kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
-                f"render_kbuffer_kernel<{head}, {1 if dom == 'BwdRender' else (2 if recording else 0)}>"
+                (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
+                 f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>" if win <= 16 else f"render_kbuffer_kernel<{win}, {2 if recording else 0}>")
         else:
             kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
         prof, prof_note = profile_entry(kname, f"{args.workload}-{args.variant}")
