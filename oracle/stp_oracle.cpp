@@ -211,6 +211,10 @@ inline M3 compute_cov2D_full(V3 t, float fx, float fy, float tan_fovx, float tan
 // Canonical evaluation order (shared with the HIP kernels so that depth keys compare bit-for-bit):
 // every dot product is fma(c, z, fma(b, y, a*x)) with correctly rounded fused multiply-adds, the
 // reciprocal is the IEEE quotient 1/x.  (The CUDA reference lets nvcc contract these sums as it likes.)
+int g_lazy_pop = 0;   // test-only switch "lazy_pop": a candidate that FAILS its tests is not shown to the pixel at all (no
+                      // pop-before-look for it) -- the claim the wave64 kernels rest on (stp_render_hier.inc filter_push,
+                      // stp_render_kbuf.hip) is that this changes no image, no final_T and no gradient; tests/test_oracle_cpu.py
+                      // holds the oracle to it bit for bit.  (n_contrib of the k-buffer counts looked-at entries and does change.)
 int g_ieee_depth = 0; // test-only switch "ieee_depth": the reference's expression with NO contraction (every product and
                       // sum rounded separately, in the order stopthepop_common.cuh:47-51 writes them) -- what the
                       // -ffp-contract=off build of the reference itself (oracle/_ref/libstp_ref_ieee.so) computes.
@@ -817,8 +821,10 @@ void render_kbuffer(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, con
                     win.pop();
                 };
                 for (uint32_t k = r0; k < r1 && !done; k++) {
-                    if (win.num == WIN) blend_one();
-                    if (done) break;
+                    if (!g_lazy_pop) {
+                        if (win.num == WIN) blend_one();
+                        if (done) break;
+                    }
                     contributor++;
                     const int id = (int)f.point_list[k];
                     if (id < 0) break; // ref: resorted_render.cuh:152-158 (never reached for valid tiles)
@@ -826,6 +832,10 @@ void render_kbuffer(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, con
                     if (!eval_alpha(f, id, px, py, G, alpha)) continue;
                     const float depth = depth_along_ray(&f.cov3D_inv[12 * (size_t)id], dir);
                     if (depth < 0.0f) continue;
+                    if (g_lazy_pop) { // (test switch: the pop only in front of a candidate that passed)
+                        if (win.num == WIN) blend_one();
+                        if (done) break;
+                    }
                     win.insert(depth, id, BACKWARD ? G : alpha);
                 }
                 if (!done) while (win.num > 0 && !done) blend_one();
@@ -940,13 +950,17 @@ struct HierSubTile {
             const int id = F4[inner].id;
             for (int l = 0; l < 4; l++) {
                 HierPixel<BACKWARD>& p = pix[m][l];
-                if (p.head.num >= HEAD) blend_front(p); // before the candidate is looked at
+                if (!g_lazy_pop && p.head.num >= HEAD) blend_front(p); // before the candidate is looked at
                 if (checkvalid && id == -1) continue;
                 if (!p.active) continue;
                 const float depth = depth_along_ray(&f->cov3D_inv[12 * (size_t)id], p.dir);
                 if (depth < 0.0f) continue;
                 float G, alpha;
                 if (!eval_alpha(*f, id, p.px, p.py, G, alpha)) continue;
+                if (g_lazy_pop) { // (test switch: the pop only in front of a candidate that passed)
+                    if (p.head.num >= HEAD) blend_front(p);
+                    if (!p.active) continue;
+                }
                 p.head.insert(depth, id, BACKWARD ? G : alpha);
             }
         }
@@ -1558,6 +1572,7 @@ void orc_set_flag(const char* name, int value)
 {
     if (name && std::string(name) == "ewa_exact_grad") g_ewa_exact_grad = value;
     if (name && std::string(name) == "ieee_depth") g_ieee_depth = value;
+    if (name && std::string(name) == "lazy_pop") g_lazy_pop = value;
 }
 
 int orc_num_threads(void)

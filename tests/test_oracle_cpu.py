@@ -83,6 +83,37 @@ def test_modes_differ_at_high_density_in_the_expected_ranking():
     assert p_hier > p_global + 10 and p_kbuf > p_global + 10
 
 
+@pytest.mark.parametrize("sd", [settings_dict(3), settings_dict(3, h44=True), settings_dict(**FULL_STP), settings_dict(3, per_pixel=8, tile_2x2=12),
+                                settings_dict(3, per_pixel=16, tile_2x2=20, h44=True), settings_dict(2, per_pixel=1), settings_dict(2, per_pixel=4),
+                                settings_dict(2, per_pixel=16), settings_dict(2, per_pixel=24)],
+                         ids=["hier", "hier_cull", "full_stp", "hier_8_12", "hier_16_20_cull", "kbuf1", "kbuf4", "kbuf16", "kbuf24"])
+def test_failing_candidates_are_no_ops_for_the_blend_order(sd):
+    """The claim the wave64 render kernels rest on (stp_render_hier.inc "filter_push", stp_render_kbuf.hip): the reference
+    pops a full head queue / k-buffer window BEFORE it looks at a candidate (ref: hierarchical_render.cuh:455-458,
+    resorted_render.cuh:17-221), but a candidate that then FAILS its tests might as well never have been shown to the pixel --
+    the next passing candidate pops the same front entry before it is inserted.  The oracle's test switch "lazy_pop" walks the
+    lists that way; image, final_T and every gradient must be bit-identical to the reference walk, in dense scenes where
+    most pixels saturate (in the list and in the final drain) as well as in sparse ones."""
+    for kw in (dict(P=6000, W=96, H=80, sigma_min=2.0, sigma_max=14.0, seed=11, camera="orbit"),
+               dict(P=1500, W=112, H=64, sigma_min=1.0, sigma_max=6.0, seed=23),
+               dict(P=9000, W=64, H=48, sigma_min=3.0, sigma_max=20.0, seed=5, camera="orbit", opacity_range=(0.01, 0.08))):
+        sc = scenes.make_scene(**kw)
+        a = orc.forward_scene(sc, sd)
+        ga = a.backward(sc.dL_dout)
+        fa_T, fa_c = a.array("final_T").copy(), a.color.copy()
+        orc.set_flag("lazy_pop", 1)
+        try:
+            b = orc.forward_scene(sc, sd)
+            gb = b.backward(sc.dL_dout)
+        finally:
+            orc.set_flag("lazy_pop", 0)
+        assert np.array_equal(fa_c.view(np.uint32), b.color.view(np.uint32))
+        assert np.array_equal(fa_T.view(np.uint32), b.array("final_T").view(np.uint32))
+        for k in ga:
+            if ga[k] is not None and np.size(ga[k]):
+                assert np.array_equal(np.ascontiguousarray(ga[k]).view(np.uint8), np.ascontiguousarray(gb[k]).view(np.uint8)), k
+
+
 def test_load_balancing_flag_changes_nothing():
     sc = scenes.make_scene(P=800, W=128, H=96, sigma_min=2.0, sigma_max=30.0, seed=3)
     a = orc.forward_scene(sc, settings_dict(**{**FULL_STP, "lb": False}))
