@@ -311,7 +311,7 @@ def main():
             win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
             kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
                 (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
-                 f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>" if win <= 16 else f"render_kbuffer_kernel<{win}, {2 if recording else 0}>")
+                 f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>")
         else:
             kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
         prof, prof_note = profile_entry(kname, f"{args.workload}-{args.variant}")

@@ -9,7 +9,7 @@
 // FAILS the tests can only cost the pixel a pop of the window's front -- which the next passing entry would have popped
 // anyway before being inserted, and which a second failing entry no longer finds.  The sequence of blended entries is
 // therefore the same whichever of the failing entries a pixel is shown, and a pixel's work is "its passing entries, in list
-// order".  The previous kernel (stp_render_tile.hip, still the re-sorting BACKWARD and the large windows) walked the whole
+// order".  The previous kernel (stp_render_tile.hip, still the re-sorting BACKWARD; STP_KBUFFER=tile selects its forward) walked the whole
 // list with all 64 lanes of a wave on the same entry: 600 cycles for every entry that reached any of the wave's 64 pixels,
 // a third of the lanes doing anything.  Here:
 //
@@ -45,7 +45,7 @@ __device__ __forceinline__ int kb_remap_tile(int wg, int n_wg)
 
 constexpr int KBW_FWD = 0, KBW_RECORD = 2, KBW_DEPTH = 3; // (the values of the hierarchical kernel's modes)
 
-template <int WIN> constexpr int kb_waves() { return WIN <= 4 ? 4 : 3; } // waves per SIMD the kernel is compiled for
+template <int WIN> constexpr int kb_waves() { return WIN <= 4 ? 4 : WIN <= 16 ? 3 : 2; } // waves per SIMD the kernel is compiled for
 
 template <int WIN, int MODE, bool FRCP>
 __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kernel(const RenderArgs a)
@@ -281,8 +281,8 @@ template <int WIN, int MODE> hipError_t launch_kb_win(const FrameParams& f, cons
 
 } // namespace
 
-// mode: 0 forward, 2 recording forward, 3 depth visualisation.  *handled = false: this window size stays with the kernel of
-// stp_render_tile.hip (windows above 16 entries: the window would not fit the register file next to the head step)
+// mode: 0 forward, 2 recording forward, 3 depth visualisation.  Every window size of the reference's ladder (forward.cu:409-425)
+// has a kernel here: four waves per SIMD up to 4 entries, three up to 16, two for 20 and 24 (164-187 VGPRs, no scratch)
 hipError_t launch_kbuffer_wave(int mode, const FrameParams& f, const RenderArgs& a, hipStream_t st, bool* handled)
 {
     const int w = f.s.queue_per_pixel; // reference forward.cu:409-425: the next supported window
@@ -294,9 +294,9 @@ hipError_t launch_kbuffer_wave(int mode, const FrameParams& f, const RenderArgs&
     if (w <= 8) STP_KBW(8);
     if (w <= 12) STP_KBW(12);
     if (w <= 16) STP_KBW(16);
+    if (w <= 20) STP_KBW(20);
+    STP_KBW(24);
 #undef STP_KBW
-    *handled = false;
-    return hipSuccess;
 }
 
 } // namespace stp

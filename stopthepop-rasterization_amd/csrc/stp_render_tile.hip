@@ -455,8 +455,8 @@ hipError_t launch_render_forward(const FrameParams& f, const GeometryState& g, c
         hipLaunchKernelGGL(render_global_fwd_kernel, grid, block, 0, st, a);
         return hipGetLastError();
     case MODE_KBUFFER: {
-        // windows up to 16 entries: the wave64 kernel of stp_render_kbuf.hip (STP_KBUFFER=tile keeps the one-entry-per-wave
-        // kernel of this file for comparison; the results are the same)
+        // the wave64 kernel of stp_render_kbuf.hip (STP_KBUFFER=tile keeps the one-entry-per-wave kernel of this file for
+        // comparison; the results are the same)
         static const char* const kb_env = std::getenv("STP_KBUFFER");
         static const bool kb_tile = kb_env && std::strcmp(kb_env, "tile") == 0;
         if (!kb_tile) {
