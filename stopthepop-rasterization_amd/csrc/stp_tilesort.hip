@@ -12,6 +12,7 @@
 // 8-bit counting passes (id bytes first when the segment is not in id order yet, then the four depth bytes) through the
 // otherwise unused unsorted arrays.  Same sorted list, bit for bit.
 #include "stp_internal.h"
+#include <rocprim/block/block_radix_sort.hpp>
 
 namespace stp {
 
@@ -45,10 +46,47 @@ __device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int
     a.entF[i] = make_float4(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2], 0.0f);
 }
 
+// Segments of 1025 .. 4096 entries that arrive in Gaussian-id order (the tile-bit radix sort is stable): a stable sort on the
+// 32 depth bits alone leaves equal depths in id order, i.e. IS the (depth, id) order -- rocPRIM's workgroup radix sort, four
+// 8-bit passes over IPT keys per thread, instead of the bitonic network's 66 / 78 barrier-separated stages on 64-bit keys
+// (which cost 0.58 ms per C3 frame and 0.78 ms per C5 frame, the third-largest kernel there).  Blocked arrangement in
+// (thread t holds entries t * IPT ...: that is the order the sort is stable in), striped out (coalesced stores).
+template <int IPT> struct TileRadix {
+    using Sort = rocprim::block_radix_sort<uint32_t, 256, IPT, uint32_t>;
+    template <class WriteEntry>
+    static __device__ __forceinline__ void run(typename Sort::storage_type& st, uint64_t* keys, uint32_t* list, int n, int tid, WriteEntry&& write_entry_at)
+    {
+        const uint64_t tile_bits = keys[0] & 0xFFFFFFFF00000000ull;
+        uint32_t k[IPT], v[IPT];
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const int i = tid * IPT + j;
+            k[j] = i < n ? (uint32_t)keys[i] : 0xFFFFFFFFu; // (a depth is a non-negative float: its bits stay below the padding)
+            v[j] = i < n ? list[i] : 0xFFFFFFFFu;
+        }
+        __syncthreads(); // (every thread has read its part of the segment before anybody overwrites it)
+        Sort().sort_to_striped(k, v, st, 0, 32);
+#pragma unroll
+        for (int j = 0; j < IPT; j++) {
+            const int i = j * 256 + tid;
+            if (i < n) {
+                keys[i] = tile_bits | k[j];
+                list[i] = v[j];
+                write_entry_at(i, (int)v[j]);
+            }
+        }
+    }
+};
+
 template <int CAP, int MIN_N>
 __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArgs a)
 {
-    __shared__ uint64_t s_key[CAP]; // (depth bits << 32) | Gaussian id
+    using Radix8 = TileRadix<8>;
+    using Radix16 = TileRadix<16>;
+    constexpr size_t RADIX_BYTES = CAP == TS_CAP ? (sizeof(typename Radix16::Sort::storage_type) > sizeof(typename Radix8::Sort::storage_type) ? sizeof(typename Radix16::Sort::storage_type) : sizeof(typename Radix8::Sort::storage_type)) : 0;
+    constexpr size_t RAW_BYTES = RADIX_BYTES > sizeof(uint64_t) * CAP ? RADIX_BYTES : sizeof(uint64_t) * CAP;
+    __shared__ __attribute__((aligned(16))) char s_raw[RAW_BYTES]; // the bitonic network's keys, or the radix sort's exchange area
+    uint64_t* const s_key = reinterpret_cast<uint64_t*>(s_raw); // (depth bits << 32) | Gaussian id
     __shared__ int s_cnt[3 * 256];  // long segments only: digits of a chunk, histogram, bases
     const int tid = (int)threadIdx.x;
     // XCD-aware tile order (same map as the render kernels): workgroup ids are dealt round-robin to the 8 XCDs, so each XCD gets
@@ -62,6 +100,14 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
     uint64_t* const keys = a.keys + range.x;
     uint32_t* const list = a.point_list + range.x;
 
+    if constexpr (CAP == TS_CAP) {
+        if (n <= CAP && a.id_passes == 0) { // (segments in id order: always, unless the list was binned through atomic cursors)
+            auto we = [&](int i, int id) __attribute__((always_inline)) { if (a.gpack) write_entry(a, (size_t)range.x + i, id); };
+            if (n <= 2048) Radix8::run(*reinterpret_cast<typename Radix8::Sort::storage_type*>(s_raw), keys, list, n, tid, we);
+            else Radix16::run(*reinterpret_cast<typename Radix16::Sort::storage_type*>(s_raw), keys, list, n, tid, we);
+            return;
+        }
+    }
     if (n <= CAP) {
         int m = 2;
         while (m < n) m <<= 1;
