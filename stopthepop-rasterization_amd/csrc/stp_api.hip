@@ -252,6 +252,35 @@ MailboxRing g_mailboxes[MAX_DEVICES];
 std::mutex g_mailbox_mutex;
 std::atomic<uint32_t> g_last_R[MAX_DEVICES]; // tile-list entries of the previous forward on each device (binning-size guess)
 
+// A second stream per device for the SH -> RGB kernel: nothing before the entry gather needs the colours, so the kernel (a
+// pure HBM stream, 70 us at C2) runs BESIDE the host hand-over, duplicate and the tile-bit sort (atomics, small launches and
+// 1.6 TB/s radix passes) instead of in front of them.  It starts behind the mailbox event and is joined back into the
+// caller's stream before the first reader of the colours -- and on every early return, so the caller's buffers are never
+// touched by work the caller's stream does not know about.  STP_SIDE_STREAM=0: everything on the caller's stream.
+struct SideStream { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool ready = false; };
+SideStream g_side[MAX_DEVICES];
+SideStream* side_stream(int device)
+{
+    static const char* const env = std::getenv("STP_SIDE_STREAM");
+    static const bool off = env && std::strcmp(env, "0") == 0;
+    if (off || device < 0 || device >= MAX_DEVICES) return nullptr;
+    SideStream& s = g_side[device];
+    if (!s.ready) {
+        std::lock_guard<std::mutex> lock(g_mailbox_mutex);
+        if (!s.ready) {
+            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            s.ready = true;
+        }
+    }
+    return &s;
+}
+struct SideJoin { // joins the side stream's work into `st` when it goes out of scope, unless done earlier
+    SideStream* s; hipStream_t st; bool pending;
+    hipError_t join() { if (!pending) return hipSuccess; pending = false; return hipStreamWaitEvent(st, s->done, 0); }
+    ~SideJoin() { (void)join(); }
+};
+
 int acquire_mailbox(Mailbox* out)
 {
     int device = 0;
@@ -452,7 +481,14 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     if (int rc = acquire_mailbox(&mb)) return rc;
     STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, st), "mailbox launch");
     STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
-    STP_TRY(launch_sh_color(f, g, radii, st), "SH colour launch");
+    SideStream* const side = side_stream(mb.device);
+    SideJoin colours{side, st, false};
+    if (side) {
+        STP_TRY(hipStreamWaitEvent(side->stream, mb.ev, 0), "side stream wait");
+        STP_TRY(launch_sh_color(f, g, radii, side->stream), "SH colour launch");
+        STP_TRY(hipEventRecord(side->done, side->stream), "record colour event");
+        colours.pending = true;
+    } else STP_TRY(launch_sh_color(f, g, radii, st), "SH colour launch");
     // the binning buffer is requested BEFORE the wait, sized by the previous frame's count on this device (+12.5 %): in
     // the steady state of training or serving no allocator callback runs between the kernels.  The exact-size request of
     // the reference follows only when the guess was too small (STP_BINNING=exact: always).
@@ -494,6 +530,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         STP_TRY(launch_ranges(f, b, img, R, st), "tile ranges");
         STP_DEBUG_SYNC("ranges");
     }
+    STP_TRY(colours.join(), "join colour stream"); // (the entry gather -- or, in GLOBAL mode, the render kernel -- reads the colours)
     if (tile_local_sort) STP_TRY(launch_tile_sort_gather(f, g, b, img, R, atomic_bin, st), "tile sort + entry gather");
     else STP_TRY(launch_gather_entries(f, g, b, R, st), "entry gather");
     STP_DEBUG_SYNC("entry gather");
