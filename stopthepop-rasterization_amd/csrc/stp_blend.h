@@ -48,6 +48,9 @@ struct RenderArgs {
 // ones and halve the log); a tile whose list is longer than LOG_MAX_LIST is flagged like a log overflow.
 typedef uint16_t log_t;
 constexpr int LOG_MAX_LIST = 65535;
+#ifndef STP_LOG_PACK
+#define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured)
+#endif
 constexpr int BLEND_LOG_DEPTH = 256; // records per pixel the log can hold (2 B each: 512 B per pixel)
 
 struct FwdPixel {

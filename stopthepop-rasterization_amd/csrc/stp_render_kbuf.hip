@@ -84,11 +84,31 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     // blend log (recording forward): as in stp_render_hier.inc
     char* const log_wave = RECORD ? reinterpret_cast<char*>(a.blend_log) + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 * sizeof(log_t) : nullptr;
     constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
+#if STP_LOG_PACK
+    // packed log: a lane holds the first record of a pair and stores both as one dword -- every store of a wave that is in
+    // step is a full 256-byte row
+    uint32_t log_off = (uint32_t)lane * 4u; // byte offset of my dword in the current pair row (+ 256 per completed pair)
+    int log_held = -1;                      // first record of the current pair, -1: none
+    auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
+        const bool second = log_held >= 0;
+        if (upd && second && log_off < (BLEND_LOG_DEPTH / 2) * 256u)
+            *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held | ((uint32_t)pay << 16);
+        log_off += (upd && second) ? 256u : 0u;
+        log_held = upd ? (second ? -1 : pay) : log_held;
+    };
+    auto log_records = [&]() __attribute__((always_inline)) -> int { return 2 * (int)(log_off >> 8) + (int)(log_held >= 0); };
+    auto log_finish = [&]() __attribute__((always_inline)) { // the odd last record
+        if (log_held >= 0 && log_off < (BLEND_LOG_DEPTH / 2) * 256u) *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held;
+    };
+#else
     uint32_t log_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
     auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
         if (upd && log_off < BLEND_LOG_DEPTH * LOG_ROW) *reinterpret_cast<log_t*>(log_wave + log_off) = (log_t)pay;
         log_off += upd ? LOG_ROW : 0u;
     };
+    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_off / LOG_ROW); };
+    auto log_finish = [&]() __attribute__((always_inline)) {};
+#endif
 
     Window<WIN> head;
     head.init_padded();
@@ -253,10 +273,11 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
         cfull = total; // (only the drain's first pop can be the one "in front of the next entry")
     }
 
+    if constexpr (RECORD) log_finish();
     if (inside) {
         const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
         a.final_T[pid] = fp.T;
-        a.n_contrib[pid] = RECORD ? (uint32_t)(log_off / LOG_ROW) : (uint32_t)contrib; // (recording forward: the pixel's number of log records)
+        a.n_contrib[pid] = RECORD ? (uint32_t)log_records() : (uint32_t)contrib; // (recording forward: the pixel's number of log records)
         if constexpr (DEPTHVIZ) {
             a.out_color[pid] = depth_acc;
             a.out_color[N + pid] = fp.T;
@@ -267,7 +288,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
         }
     }
     if constexpr (RECORD) {
-        if ((int)(log_off / LOG_ROW) > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u; // log overflow: this tile's backward re-sorts
+        if (log_records() > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u; // log overflow: this tile's backward re-sorts
     }
 }
 

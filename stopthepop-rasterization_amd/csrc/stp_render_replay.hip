@@ -103,7 +103,11 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
     constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
     auto log_at = [&](uint32_t k) __attribute__((always_inline)) -> int { // record k of this lane
+#if STP_LOG_PACK
+        return (int)*reinterpret_cast<const log_t*>(log_wave + (2u * lane_off + (k >> 1) * 256u + (k & 1u) * 2u)); // [record / 2][lane] of u32, low half first
+#else
         return (int)*reinterpret_cast<const log_t*>(log_wave + (lane_off + k * LOG_ROW));
+#endif
     };
     const float pxf = (float)px, pyf = (float)py;
     const float4* const eC = a.entC + range.x; // list-ordered entry records: mean + Gaussian id, conic + opacity, colour
