@@ -10,12 +10,12 @@ rect/tight/tile-based/4x4 culling + load balancing, `--variant min` = plain Z or
 resident in HBM, through the public drop-in API (GaussianRasterizer -> autograd -> _C -> C ABI).
 Rank 0 prints ONE JSON line (contract in the task statement / DESIGN.md section "Measurement").
 
-N > 1: the unit of the metric is a frame, and frames are independent, so the C2 headline shards FRAMES over the ranks
-(`--shard frames`): every rank renders its own frame, no data-path collective, weak scaling.  The same run then also
-times the north star's tile-row mode -- ONE frame partitioned by screen-tile row, image strips sent to rank 0 over RCCL,
-per-Gaussian gradient records all-reduced (strong scaling) -- and reports it in the `tile_shard` object of the JSON
-line (`--no-tile-shard-probe` leaves it out).  `--shard tilerows` makes that mode the headline; it is the default for
-`--workload C4`, BASELINE's 4K serving configuration.
+N > 1: the north star's tile-row mode is the headline -- ONE frame partitioned by screen-tile row over the N ranks, image
+strips sent to rank 0 over RCCL, per-Gaussian gradient records all-reduced: `"scaling": "strong"`, `value` = frames/s of
+that one frame stream (`--shard tilerows`, the default for every workload).  The same run then also times the
+frame-sharded mode (every rank its own frame, no data-path collective, weak scaling) and reports it in the
+`frame_shard` object of the JSON line (`--no-frame-shard-probe` leaves it out); `--shard frames` swaps the two.
+`rccl_ranks` is what the first collective of the run saw.
 
 The `cpu_baseline` leg (rank 0, N == 1 only) times the CPU oracle on a bounded sample of the same frame:
 it is a reported, non-target baseline.
@@ -129,6 +129,228 @@ def profile_entry(kernel: str, workload: str):
     return (e, t.get("_taken", "")) if e else (None, f"no PMC profile of {kernel} for {workload}")
 
 
+class Workload:
+    """One BASELINE configuration resident in HBM: tensors, the drop-in rasterizer module, one step() = one pass of the hot path."""
+
+    def __init__(self, name, variant, dev, fwd_only=False, scale=1.0, dist=None, rank=0, world=1, sharded=False, train_forward_only=False):
+        import diff_gaussian_rasterization as dgr
+        from diff_gaussian_rasterization import _C, scenes, tile_shard
+        self.name, self.variant, self.dev = name, variant, dev
+        self.fwd_only = fwd_only or name == "C4"
+        self.scale, self.world, self.sharded = scale, world, sharded
+        self.train_forward_only = train_forward_only
+        self._C = _C
+        self.scene = scene = scenes.config(name, scale=scale)
+        self.es = es = settings_for(variant, name)
+        self.sdict = es.to_dict()
+        fo = self.fwd_only
+        t = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev).requires_grad_(rg and not fo)
+        self.means3D, self.opac = t(scene.means3D, True), t(scene.opacities, True)
+        self.scales, self.rots, self.shs = t(scene.scales, True), t(scene.rotations, True), t(scene.shs, True)
+        self.means2D = torch.zeros_like(self.means3D, requires_grad=not fo)
+        self.w_img = t(scene.dL_dout)
+        self.rs = dgr.GaussianRasterizationSettings(
+            image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
+            scale_modifier=1.0, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix),
+            inv_viewprojmatrix=t(scene.inv_viewprojmatrix), sh_degree=scene.sh_degree, campos=t(scene.campos),
+            prefiltered=False, settings=es, render_depth=False, debug=False)
+        self.gy = (scene.H + 15) // 16
+        self.raster = tile_shard.TileRowShardedRasterizer(self.rs, dist, rank, world) if sharded else dgr.GaussianRasterizer(self.rs)
+        self.leaves = [self.means3D, self.means2D, self.opac, self.scales, self.rots, self.shs]
+        self.state = {}
+        self.label = f"{name}-{variant}" if name in ("C2", "C2L", "C4", "C5", "L1") else name
+
+    def tensors(self):
+        return (self.means3D, self.means2D, self.opac, self.shs, self.scales, self.rots)
+
+    def step(self):
+        for x in self.leaves:
+            if x is not None and x.grad is not None:
+                x.grad = None
+        color, radii = self.raster(self.means3D, self.means2D, self.opac, shs=self.shs, scales=self.scales, rotations=self.rots)
+        self.state["color"], self.state["radii"] = color, radii
+        if not self.fwd_only and not self.train_forward_only:
+            (color * self.w_img).sum().backward()
+        elif self.train_forward_only:  # nobody will replay this log: hand the buffers back
+            self._C.release_scratch(color.grad_fn.saved_tensors[11]); self._C.release_scratch(color.grad_fn.saved_tensors[10])
+
+    def free(self):
+        self.state.clear()
+        for x in self.leaves:
+            if x is not None:
+                x.grad = None
+        self.leaves = []
+        self.raster = None
+
+
+def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
+    """W untimed warm-up steps, then EXACTLY `steps` steps between two barriers (+ device synchronisation).  Returns wall
+    seconds, the library's per-stage hipEvent means over the region, and the per-step intervals between hipEvents recorded on
+    the launch stream after every step (no synchronisation inside the region)."""
+    _C, dev = wl._C, wl.dev
+    # bring the device out of its idle power state before the contract's W warm-up steps: the first process on a fresh box
+    # otherwise measures the clock ramp (seen: 299 instead of 337 frames/s); untimed, like the warm-up itself
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < prewarm_seconds:
+        wl.step()
+        torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        wl.step()
+    barrier()
+    import gc
+    gc.collect()
+    gc.disable()  # (a collection inside the timed region is a multi-millisecond stall of the launching thread)
+    _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    stream = torch.cuda.current_stream(dev)
+    t0 = time.perf_counter()
+    marks[0].record(stream)
+    cum = []
+    for i in range(steps):
+        wl.step()
+        marks[i + 1].record(stream)
+        if per_step:  # debug: per-step wall time (adds a sync per step, invalidates the headline number)
+            torch.cuda.synchronize(dev)
+            cum.append(round(1000.0 * (time.perf_counter() - t0), 3))
+    barrier()
+    dt = time.perf_counter() - t0
+    gc.enable()
+    stage_ms = {k: v for k, v in _C.timing_read(dev).items() if v >= 0}  # means over the timed region
+    _C.timing_enable(False)
+    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    stats = {"median": round(per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]), 4),
+             "min": round(per[0], 4), "max": round(per[-1], 4),
+             "how": "intervals between hipEvents recorded on the launch stream after every step of the timed region"} if per else {}
+    return dt, stage_ms, stats, cum
+
+
+def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
+    """Sizes of the frame (from one extra untimed forward), SURVEY 8(d) byte models, the dominant kernel and its roofline."""
+    _C, scene, sdict, rs, fwd_only = wl._C, wl.scene, wl.sdict, wl.rs, wl.fwd_only
+    radii = wl.state["radii"]
+    P = scene.P
+    P_v = int((radii > 0).sum().item())
+    N = scene.W * scene.H
+    T = ((scene.W + 15) // 16) * wl.gy
+    mode = int(sdict["sort_settings"]["sort_mode"])
+    order = int(sdict["sort_settings"]["sort_order"])
+    S = 1 if (mode != 0 or order >= 2) else 0
+    Kf = 1 if order >= 2 else 0
+    E = 1 if (sdict["culling_settings"]["tile_based_culling"] or order == 3) else 0
+    ewa = bool(sdict["proper_ewa_scaling"])
+    head, mid = int(sdict["sort_settings"]["queue_sizes"]["per_pixel"]), int(sdict["sort_settings"]["queue_sizes"]["tile_2x2"])
+    cull = bool(sdict["culling_settings"]["hierarchical_4x4_culling"])
+    recording = mode in (2, 3) and not fwd_only and _C.backward_mode() != "resort" and not wl.sharded and recording_allowed
+    # R (tile-list entries) and B (blended (pixel, entry) pairs) from ONE extra untimed forward through _C directly: a
+    # forward-only run has no grad_fn to ask, and the timed graphs are gone
+    empty = torch.Tensor([])
+    d1 = dict(sdict)
+    if recording:
+        d1["_record_blend_log"] = True
+    o1 = _C.rasterize_gaussians(rs.bg, wl.means3D.detach(), empty, wl.opac.detach(), wl.scales.detach(), wl.rots.detach(), 1.0, empty,
+                                rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                rs.image_width, wl.shs.detach(), rs.sh_degree, rs.campos, False, d1, False, False)
+    R = int(o1[0])
+    B = 0
+    if recording or mode in (0, 2):   # n_contrib = blends per pixel (recording forwards), list positions visited (GLOBAL / k-buffer)
+        B = int(_C.image_array(o1[5], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256 if recording else 1 << 30).sum().item())
+    _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
+    del o1
+    M = 16
+    alg = survey_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, ewa)
+    des = design_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, B if recording else 0)
+    dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
+    dom_key = "render_bwd" if dom == "BwdRender" else "render_fwd"
+    dom_ms = stage_ms.get(dom, float("nan"))
+    achieved = alg[dom_key] / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
+    if mode == 3:
+        # (last template argument: the depth keys' reciprocal without its domain check -- the default queue sizes'
+        # forward passes on a frame whose Sigma^-1 is tame, which every synthetic workload is)
+        frcp = "true" if (head == 4 and mid == 8) else "false"
+        kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
+            else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
+    elif mode == 2:
+        win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
+        kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
+            (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
+             f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>")
+    else:
+        kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
+    prof, prof_note = profile_entry(kname, f"{wl.name}-{wl.variant}")
+    fwd_keys, bwd_keys = ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"), ("zero_fill", "render_bwd", "bwd_cov2D", "bwd_preprocess")
+    fwd_bytes = sum(alg[k] for k in fwd_keys)
+    bwd_bytes = sum(alg[k] for k in bwd_keys)
+    step_bytes = fwd_bytes + (0 if fwd_only else bwd_bytes)
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(prof["hbm_bytes_per_launch"]) if prof else None,
+                "traffic_source": prof_note,
+                "algorithmic_bytes_per_launch": int(alg[dom_key]), "bytes_model": "SURVEY.md section 8(d), verbatim",
+                "design_bytes_per_launch": int(des[dom_key]), "avg_launch_ms": round(dom_ms, 4),
+                "whole_step_frac": round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5),
+                "note": "this kernel is VALU-issue bound, not HBM bound (see \"valu\"); the HBM fraction is reported because the contract asks for it"}
+    info = {"P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B, "mode": mode, "order": order,
+            "alg": alg, "des": des, "fwd_bytes": fwd_bytes, "bwd_bytes": bwd_bytes, "kname": kname, "dom_ms": dom_ms,
+            "prof": prof, "prof_note": prof_note}
+    return roofline, info
+
+
+def hbm_ceilings(dev):
+    """Measured HBM ceilings of THIS box (torch's vectorised elementwise / reduce kernels on 1 GiB fp32 tensors, best of 10):
+    what a streaming kernel can reach here, next to the 8 TB/s spec peak the roofline fractions are priced on."""
+    n = 1 << 28
+    x = torch.ones(n, device=dev); y = torch.empty_like(x)
+
+    def best(f, reps=10):
+        for _ in range(2):
+            f()
+        torch.cuda.synchronize(dev)
+        b = 1e9
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); f(); e1.record(); e1.synchronize()
+            b = min(b, e0.elapsed_time(e1))
+        return b
+    gb = n * 4 / 1e9
+    out = {"read_GBps": round(1e3 * gb / best(lambda: x.sum()), 1), "write_GBps": round(1e3 * gb / best(lambda: y.fill_(2.0)), 1),
+           "copy_GBps": round(1e3 * 2 * gb / best(lambda: y.copy_(x)), 1),
+           "how": "torch sum / fill_ / copy_ on 1 GiB fp32, best of 10, this box, this run"}
+    del x, y
+    torch.cuda.empty_cache()
+    return out
+
+
+OTHER_WORKLOADS = (("C2-min", "C2", "min", False), ("C3", "C3", "full", False), ("C4-1gpu-fwd", "C4", "full", True), ("C5", "C5", "full", False))
+
+
+def other_workloads(dev, steps=5, warmup=2):
+    """The BASELINE configurations that are not the headline, `steps` timed steps each on the same code in the same process
+    (same harness as the headline: wall clock between two synchronisations, stage hipEvents, SURVEY 8(d) bytes)."""
+    out = {}
+    for label, name, variant, fwd_only in OTHER_WORKLOADS:
+        try:
+            wl = Workload(name, variant, dev, fwd_only=fwd_only)
+            dt, stage_ms, stats, _ = timed_region(wl, steps, warmup, 0.2, lambda: torch.cuda.synchronize(dev))
+            ms = 1000.0 * dt / steps
+            roof, info = describe(wl, stage_ms, ms)
+            out[label] = {"value": round(steps / dt, 3), "unit": "frames/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
+                          "step_ms": {k: stats[k] for k in ("median", "min", "max")} if stats else {},
+                          "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+                          "P": info["P"], "num_rendered": info["num_rendered"], "blended_pairs": info["blended_pairs"],
+                          "resolution": f"{wl.scene.W}x{wl.scene.H}", "passes": "fwd" if wl.fwd_only else "fwd+bwd",
+                          "dominant_kernel": roof["kernel"], "dominant_ms": roof["avg_launch_ms"],
+                          "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "achieved_GBps": roof["achieved"],
+                          "frac": roof["frac"]}
+            wl.free()
+            del wl
+        except Exception as ex:  # the headline stands on its own
+            out[label] = {"error": repr(ex)[:300]}
+        wl = None
+        from diff_gaussian_rasterization import _C
+        _C.clear_scratch_pool(dev)
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -137,17 +359,18 @@ def main():
     ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "L1", "C2L"])
     ap.add_argument("--variant", default="full", choices=["full", "min"])
     ap.add_argument("--shard", default=None, choices=["tilerows", "frames"],
-                    help="N > 1: what the ranks share.  Default: tilerows for C4 (BASELINE's 4K serving configuration IS the tile-row shard "
-                         "with an RCCL gather), frames otherwise (the metric's unit is a frame and frames are independent)")
-    ap.add_argument("--tile-shard-probe", action="store_true", help="(accepted, no effect: the probe runs by default when N > 1)")
-    ap.add_argument("--no-tile-shard-probe", action="store_true",
-                    help="N > 1 with --shard frames: do NOT additionally time one frame sharded by tile row over all ranks (the \"tile_shard\" "
-                         "object of the JSON line; a fault in it degrades to an error field, the headline stands on its own)")
-    ap.add_argument("--probe-timeout", type=float, default=120.0, help="seconds the tile-row probe may take before the headline is printed without it")
+                    help="N > 1: what the ranks share.  Default: tilerows (north star: ONE frame partitioned by screen-tile row, strips "
+                         "gathered over RCCL, strong scaling); frames = every rank renders its own frame, no collective, weak scaling")
+    ap.add_argument("--no-frame-shard-probe", action="store_true",
+                    help="N > 1 with --shard tilerows: do NOT additionally time the frame-sharded mode (the \"frame_shard\" object of the JSON line)")
+    ap.add_argument("--tile-shard-probe", action="store_true", help="(accepted, no effect)")
+    ap.add_argument("--no-tile-shard-probe", action="store_true", help="(accepted; N > 1 with --shard frames: no tile-row side measurement)")
+    ap.add_argument("--probe-timeout", type=float, default=120.0, help="seconds the side measurement may take before the headline is printed without it")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalidates the headline number)")
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps (device clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N == 1: leave out the other_workloads object (C2-min, C3, C4 on one GPU, C5; 5 steps each)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--train-forward-only", action="store_true",
                     help="debug: forward passes that expect a backward (recording forward) without running it; read stage_ms only")
@@ -172,87 +395,39 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     dist = None
+    rccl_ranks = None
     if world > 1 or args.force_shard:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
+        # the first collective: every rank contributes 1, so the sum IS the number of ranks RCCL connected
+        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        dist.all_reduce(ones)
+        rccl_ranks = {"world_size": int(dist.get_world_size()), "all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend()}
 
-    import diff_gaussian_rasterization as dgr
-    from diff_gaussian_rasterization import _C, scenes, tile_shard
+    from diff_gaussian_rasterization import _C
 
     fwd_only = args.fwd_only or args.workload == "C4"
     if args.shard is None:
-        args.shard = "tilerows" if args.workload == "C4" else "frames"
-    scene = scenes.config(args.workload, scale=args.scale)
-    es = settings_for(args.variant, args.workload)
-    sdict = es.to_dict()
-    t = lambda a, rg=False: None if a is None else torch.tensor(a, device=dev).requires_grad_(rg and not fwd_only)
-    means3D, opac = t(scene.means3D, True), t(scene.opacities, True)
-    scales, rots, shs = t(scene.scales, True), t(scene.rotations, True), t(scene.shs, True)
-    means2D = torch.zeros_like(means3D, requires_grad=not fwd_only)
-    w_img = t(scene.dL_dout)
-    rs = dgr.GaussianRasterizationSettings(
-        image_height=scene.H, image_width=scene.W, tanfovx=scene.tanfovx, tanfovy=scene.tanfovy, bg=t(scene.bg),
-        scale_modifier=1.0, viewmatrix=t(scene.viewmatrix), projmatrix=t(scene.projmatrix),
-        inv_viewprojmatrix=t(scene.inv_viewprojmatrix), sh_degree=scene.sh_degree, campos=t(scene.campos),
-        prefiltered=False, settings=es, render_depth=False, debug=False)
-
-    gy = (scene.H + 15) // 16
+        args.shard = "tilerows"
     sharded = (world > 1 or args.force_shard) and args.shard == "tilerows"
-    if sharded:
-        raster = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
-    else:
-        raster = dgr.GaussianRasterizer(rs)
-    leaves = [means3D, means2D, opac, scales, rots, shs]
-    state = {}
-
-    def step():
-        for x in leaves:
-            if x is not None and x.grad is not None:
-                x.grad = None
-        color, radii = raster(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
-        state["color"], state["radii"] = color, radii
-        if not fwd_only and not args.train_forward_only:
-            (color * w_img).sum().backward()
-        elif args.train_forward_only:
-            _C.release_scratch(color.grad_fn.saved_tensors[11]); _C.release_scratch(color.grad_fn.saved_tensors[10])  # nobody will replay this log: hand the buffers back
+    wl = Workload(args.workload, args.variant, dev, fwd_only=fwd_only, scale=args.scale, dist=dist, rank=rank, world=world,
+                  sharded=sharded, train_forward_only=args.train_forward_only)
+    scene, sdict, es, gy = wl.scene, wl.sdict, wl.es, wl.gy
+    fwd_only = wl.fwd_only
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # bring the device out of its idle power state before the contract's W warm-up steps: the first process on a fresh box
-    # otherwise measures the clock ramp (seen: 299 instead of 337 frames/s); untimed, like the warm-up itself
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < args.prewarm_seconds:
-        step()
-        torch.cuda.synchronize(dev)
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    import gc
-    gc.collect()
-    gc.disable()  # (a collection inside the timed region is a multi-millisecond stall of the launching thread)
-    _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
-    t0 = time.perf_counter()
-    per_step = []
-    for _ in range(args.steps):
-        step()
-        if args.per_step:  # debug: per-step wall time (adds a sync per step, invalidates the headline number)
-            torch.cuda.synchronize(dev)
-            per_step.append(round(1000.0 * (time.perf_counter() - t0), 3))
-    barrier()
+    dt, stage_ms, step_stats, cum = timed_region(wl, args.steps, args.warmup, args.prewarm_seconds, barrier, per_step=args.per_step)
     if args.per_step and rank == 0:
-        print("cumulative ms after each step:", per_step, "reserved GB:", round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+        print("cumulative ms after each step:", cum, "reserved GB:", round(torch.cuda.memory_reserved(dev) / 2**30, 2),
               "num_alloc_retries:", torch.cuda.memory_stats(dev).get("num_alloc_retries"), "segments:",
               torch.cuda.memory_stats(dev).get("segment.all.allocated"), file=sys.stderr, flush=True)
-    dt = time.perf_counter() - t0
-    gc.enable()
-    stage_ms = {k: v for k, v in _C.timing_read().items() if v >= 0}  # means over the timed region
-    _C.timing_enable(False)
 
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -264,68 +439,9 @@ def main():
     ms_per_step = 1000.0 * dt / args.steps
 
     def build_out():
-        # measured sizes for the byte models
-        radii = state["radii"]
-        P = scene.P
-        P_v = int((radii > 0).sum().item())
-        N = scene.W * scene.H
-        T = ((scene.W + 15) // 16) * gy
-        mode = int(sdict["sort_settings"]["sort_mode"])
-        order = int(sdict["sort_settings"]["sort_order"])
-        S = 1 if (mode != 0 or order >= 2) else 0
-        Kf = 1 if order >= 2 else 0
-        E = 1 if (sdict["culling_settings"]["tile_based_culling"] or order == 3) else 0
-        ewa = bool(sdict["proper_ewa_scaling"])
-        head, mid = int(sdict["sort_settings"]["queue_sizes"]["per_pixel"]), int(sdict["sort_settings"]["queue_sizes"]["tile_2x2"])
-        cull = bool(sdict["culling_settings"]["hierarchical_4x4_culling"])
-        recording = mode in (2, 3) and not fwd_only and os.environ.get("STP_BACKWARD", "replay") != "resort" and not sharded
-        # R (tile-list entries) and B (blended (pixel, entry) pairs) from ONE extra untimed forward through _C directly: a
-        # forward-only run has no grad_fn to ask, and the timed graphs are gone
-        empty = torch.Tensor([])
-        d1 = dict(sdict)
-        if recording:
-            d1["_record_blend_log"] = True
-        o1 = _C.rasterize_gaussians(rs.bg, means3D.detach(), empty, opac.detach(), scales.detach(), rots.detach(), 1.0, empty,
-                                    rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
-                                    rs.image_width, shs.detach(), rs.sh_degree, rs.campos, False, d1, False, False)
-        R = int(o1[0])
-        B = 0
-        if recording or mode in (0, 2):   # n_contrib = blends per pixel (recording forwards), list positions visited (GLOBAL / k-buffer)
-            B = int(_C.image_array(o1[5], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256 if recording else 1 << 30).sum().item())
-        _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
-        del o1
-        M = 16
-        alg = survey_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, ewa)
-        des = design_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, B if recording else 0)
-        dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
-        dom_key = "render_bwd" if dom == "BwdRender" else "render_fwd"
-        dom_ms = stage_ms.get(dom, float("nan"))
-        achieved = alg[dom_key] / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
-        if mode == 3:
-            # (last template argument: the depth keys' reciprocal without its domain check -- the default queue sizes'
-            # forward passes on a frame whose Sigma^-1 is tame, which every synthetic workload is)
-            frcp = "true" if (head == 4 and mid == 8) else "false"
-            kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
-                else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
-        elif mode == 2:
-            win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
-            kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
-                (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
-                 f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>")
-        else:
-            kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
-        prof, prof_note = profile_entry(kname, f"{args.workload}-{args.variant}")
-        fwd_keys, bwd_keys = ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"), ("zero_fill", "render_bwd", "bwd_cov2D", "bwd_preprocess")
-        fwd_bytes = sum(alg[k] for k in fwd_keys)
-        bwd_bytes = sum(alg[k] for k in bwd_keys)
-        step_bytes = fwd_bytes + (0 if fwd_only else bwd_bytes)
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(prof["hbm_bytes_per_launch"]) if prof else None,
-                    "traffic_source": prof_note,
-                    "algorithmic_bytes_per_launch": int(alg[dom_key]), "bytes_model": "SURVEY.md section 8(d), verbatim",
-                    "design_bytes_per_launch": int(des[dom_key]), "avg_launch_ms": round(dom_ms, 4),
-                    "whole_step_frac": round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5),
-                    "note": "this kernel is VALU-issue bound, not HBM bound (see \"valu\"); the HBM fraction is reported because the contract asks for it"}
+        roofline, info = describe(wl, stage_ms, ms_per_step)
+        P, P_v, R, T, B, mode, order = info["P"], info["P_visible"], info["num_rendered"], info["tiles"], info["blended_pairs"], info["mode"], info["order"]
+        des, prof, prof_note, kname, dom_ms = info["des"], info["prof"], info["prof_note"], info["kname"], info["dom_ms"]
         out = {
             "metric": "fwd+bwd frames/sec at 1920×1080, 1M Gaussians; PSNR vs reference",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -337,12 +453,15 @@ def main():
                        "P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B,
                        "parallelism": (f"tilerows{world}" if sharded else f"frames{world}") if world > 1 else "single",
                        "scale": args.scale},
+            "step_ms": step_stats,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "algorithmic_bytes": {"forward": int(fwd_bytes), "backward": int(bwd_bytes), "model": "SURVEY.md section 8(d)"},
+            "algorithmic_bytes": {"forward": int(info["fwd_bytes"]), "backward": int(info["bwd_bytes"]), "model": "SURVEY.md section 8(d)"},
             "design_bytes": {"forward": int(sum(des[k] for k in ("preprocess", "scan", "duplicate", "sort", "ranges", "gather", "render_fwd"))),
                              "backward": int(sum(des[k] for k in ("zero_fill", "render_bwd", "bwd_preprocess")))},
             "roofline": roofline,
         }
+        if rccl_ranks is not None:
+            out["rccl_ranks"] = rccl_ranks
         if prof and prof.get("SQ_INSTS_VALU") and dom_ms and dom_ms > 0:
             # VALU view of the dominant kernel, from pass 1 of the same committed profile (SQ counters are sums over the chip):
             # busy = SQ_ACTIVE_INST_VALU (quad-cycles) x 4 / (1024 SIMDs x launch duration x 2.4 GHz nominal);
@@ -353,22 +472,25 @@ def main():
                            "insts_per_pair": round(64.0 * prof["SQ_INSTS_VALU"] / B, 1) if B else None,
                            "lane_util": round(prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"] / 64.0, 3),
                            "source": prof_note}
-        return out, es
+        return out
 
     out = None
     if rank == 0:
-        out, _ = build_out()
+        out = build_out()
 
-    # auxiliary measurement (N > 1): one frame sharded by tile row over all ranks.  The headline `out` is complete before it
-    # starts, and a watchdog prints it with an error field should the exchange hang (it has never run on 8 GPUs by us).
-    tile_probe = None
-    if world > 1 and not sharded and not args.no_tile_shard_probe:
+    # side measurement (N > 1): the OTHER way of sharing the N GPUs -- every rank its own frame, no data-path collective
+    # (weak scaling) when the headline is the tile-row mode, one frame by tile rows when the headline is frames.  The
+    # headline `out` is complete before it starts, and a watchdog prints it with an error field should the side run hang.
+    side, side_key = None, None
+    want_side = world > 1 and ((sharded and not args.no_frame_shard_probe) or (not sharded and not args.no_tile_shard_probe))
+    if want_side:
         import threading
+        side_key = "frame_shard" if sharded else "tile_shard"
 
         def bail():
             if rank == 0:
                 o = dict(out)
-                o["tile_shard"] = {"error": f"timed out after {args.probe_timeout:.0f} s: the tile-row exchange did not complete; the headline is unaffected"}
+                o[side_key] = {"error": f"timed out after {args.probe_timeout:.0f} s; the headline is unaffected"}
                 os.write(result_fd, (json.dumps(o) + "\n").encode())
             os._exit(0)
 
@@ -376,42 +498,46 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            r2 = tile_shard.TileRowShardedRasterizer(rs, dist, rank, world)
-
-            def step2():
-                for x in leaves:
-                    if x is not None and x.grad is not None:
-                        x.grad = None
-                color, _ = r2(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
-                if not fwd_only:
-                    (color * w_img).sum().backward()
-
+            wl2 = Workload(args.workload, args.variant, dev, fwd_only=fwd_only, scale=args.scale, dist=dist, rank=rank, world=world,
+                           sharded=not sharded)
             k2 = max(1, min(args.steps, 10))
-            for _ in range(2):
-                step2()
-            barrier()
-            t2 = time.perf_counter()
-            for _ in range(k2):
-                step2()
-            barrier()
-            dt2 = time.perf_counter() - t2
+            dt2, stage2, _, _ = timed_region(wl2, k2, 2, 0.0, barrier)
             tt2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
             dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
             dt2 = float(tt2.item())
-            tile_probe = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
-                          "scaling": "strong", "parallelism": f"tilerows{world}",
-                          "exchange": "three channel segments per peer sent straight into rank 0's frame (grouped RCCL send/recv) + all-reduce of 36 B per Gaussian"}
+            if sharded:
+                side = {"value": round(world * k2 / dt2, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * dt2 / k2, 4), "steps": k2,
+                        "scaling": "weak", "parallelism": f"frames{world}",
+                        "what": "every rank renders its own frame (the metric's unit is a frame and frames are independent): no data-path collective"}
+            else:
+                side = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
+                        "scaling": "strong", "parallelism": f"tilerows{world}",
+                        "exchange": "three channel segments per peer sent straight into rank 0's frame (grouped RCCL send/recv) + all-reduce of 36 B per Gaussian"}
+            wl2.free()
         except Exception as ex:  # the headline above stands on its own
-            tile_probe = {"error": repr(ex)[:300]}
+            side = {"error": repr(ex)[:300]}
         watchdog.cancel()
 
     if rank == 0:
-        if tile_probe is not None:
-            out["tile_shard"] = tile_probe
+        if side is not None:
+            out[side_key] = side
+        if sharded and world > 1:
+            out["tile_shard_exchange"] = ("forward: every peer sends its strip as three channel segments straight into rank 0's frame (grouped RCCL send/recv); "
+                                          "backward: all-reduce of 36 B per Gaussian between the two halves; the per-Gaussian stages run replicated "
+                                          "(DESIGN.md section 7 gives the Amdahl ceiling per N)")
+        if world == 1:
+            out["hbm_measured"] = hbm_ceilings(dev)
         if world == 1 and not args.no_cpu_baseline:
-            checker = checker_legs(scene, sdict, gy, fwd_only, args.cpu_rows, state, leaves, raster_factory=lambda e: dgr.GaussianRasterizer(rs._replace(settings=e)),
-                                   es=es, tensors=(means3D, means2D, opac, shs, scales, rots), w_img=w_img)
+            checker = checker_legs(scene, sdict, gy, fwd_only, args.cpu_rows, wl.state, wl.leaves,
+                                   raster_factory=lambda e: __import__("diff_gaussian_rasterization").GaussianRasterizer(wl.rs._replace(settings=e)),
+                                   es=es, tensors=wl.tensors(), w_img=wl.w_img)
             out.update(checker)
+        if world == 1 and not args.no_other_workloads and args.workload == "C2" and args.variant == "full" and args.scale == 1.0 \
+                and not args.fwd_only and not args.train_forward_only:
+            wl.free()
+            _C.clear_scratch_pool(dev)
+            torch.cuda.empty_cache()
+            out["other_workloads"] = other_workloads(dev)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     os.close(result_fd)
     if dist is not None:
@@ -475,7 +601,9 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
     sl = slice(16 * y0, min(16 * (y0 + nrows), scene.H))
     img_p = cw.detach().cpu().numpy()[:, sl]
     img_o = ofr.color[:, sl]
-    par = {"against": "CPU oracle (held bit-for-bit to the reference's own IEEE build in all integer / state results: tests/test_reference_golden.py)",
+    par = {"against": "CPU oracle; the oracle is held bit-for-bit in all integer / state results to the reference's own sources built for gfx950 by "
+                      "hipify-perl + a 40-line adapter header + hipcc -ffp-contract=off (tests/test_reference_golden.py) -- NOT an nvcc build: by the "
+                      "tier rules that pin counts as 'parity unpinned / partial'",
            "window": f"tile rows {y0}..{y0 + nrows - 1} of {gy} of the timed frame",
            **_img_err(img_p, img_o)}
     if not fwd_only:

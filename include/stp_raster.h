@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 4
+#define STP_ABI_VERSION 5
 #define STP_GRAD_RECORD_FLOATS 16 /* floats per Gaussian in grad_records (see stp_backward) */
 
 /* Replaces CudaRasterizer::SplattingSettings + SortSettings + SortQueueSizes + CullingSettings
@@ -80,7 +80,14 @@ typedef enum StpStatus {
 
 /* Replaces the three `std::function<char*(size_t)>` buffer-resize callbacks of Rasterizer::forward
    (rasterizer.h:196-198; rasterize_points.cu:33-41).  Must return a device pointer to at least
-   `bytes` bytes, valid until the matching backward has run. */
+   `bytes` bytes, valid until the matching backward has run.
+   geometry_alloc and image_alloc are called once per forward.  binning_alloc may be called TWICE: once before the
+   num_rendered hand-over with a size guessed from the previous frame of the same kind on this device (P, resolution,
+   tile-row window, sort mode; count + 12.5 %), and again with the exact -- larger -- size only when the guess was too
+   small.  The SECOND block replaces the first (resize semantics, as the reference's callback has): an arena / bump
+   allocator must be prepared to take the first block back, and the buffer it finally hands to stp_backward is the
+   one of the LAST call.  A guessed request can exceed the exact size by up to 12.5 % (+ the change of num_rendered from
+   frame to frame); STP_BINNING=exact in the environment restores the reference's single exact request. */
 typedef void* (*stp_alloc_fn)(void* user, size_t bytes);
 
 /* Replaces CudaRasterizer::Rasterizer::forward (rasterizer.h:195-220, rasterizer_impl.cu:221-413).
@@ -171,8 +178,10 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
    "Preprocess","Duplicate","Sort","Render", rasterizer_impl.cu:248) plus "BwdRender","BwdPreprocess".
    While enabled, every forward/backward records hipEvents around its stages on the call's stream (no extra
    host synchronisation); stp_timing_read waits for the recorded events and returns the MEAN milliseconds per
-   stage over the calls since stp_timing_enable(1) (6 floats, unmeasured stages are -1).  One process-wide timer: enable
-   it from one thread only (the rest of the API is re-entrant). */
+   stage over the calls since stp_timing_enable(1) (6 floats, unmeasured stages are -1).  One timer PER DEVICE behind a
+   mutex: stp_timing_read / stp_timing_text report the calling thread's CURRENT device (hipSetDevice first); a backward is
+   attributed to the latest forward of its device, so time one caller per device.  stp_timing_read returns STP_ERR_HIP
+   when an event could not be created or recorded (the timings are then incomplete). */
 void stp_timing_enable(int enabled);
 int stp_timing_read(float* ms6);
 /* The text the reference hands to the SIBR viewer (DebugVisualizationData::timings_text, rasterizer_impl.cu:391-399):

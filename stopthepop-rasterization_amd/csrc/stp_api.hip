@@ -7,9 +7,12 @@
 // num_rendered) -> duplicate -> sort -> tile ranges -> render, where "sort" is by default a radix sort on the tile bits
 // followed by the per-tile (depth, id) sort fused with the entry gather (stp_tilesort.hip; STP_SORT selects the
 // alternatives, see stp_forward).  Everything is enqueued on the caller's stream; the only host synchronisation is
-// the read-back.  The calls are re-entrant (no shared mutable state: the scratch buffers belong to the caller,
-// stp_last_error is per thread) EXCEPT for the optional stage timer, which is one process-wide instance meant for a
-// single timed caller (bench.py, the viewer's timings text).
+// the read-back.  The calls are re-entrant: the scratch buffers belong to the caller, stp_last_error is per thread, the
+// per-device helpers (mailbox ring, side stream, binning-size guesses) are created once behind acquire/release flags,
+// and the optional stage timer is one instance PER DEVICE behind a mutex (a backward is attributed to the latest
+// forward of its device: meant for one timed caller per device -- bench.py, the viewer's timings text).
+// Environment switches (STP_SORT, STP_BINNING, STP_SIDE_STREAM, STP_KBUFFER) select code paths and are read ONCE, at the
+// first forward of the process.
 #include "stp_internal.h"
 
 #include <atomic>
@@ -245,19 +248,35 @@ using namespace stp;
 // ---- num_rendered mailbox: host-mapped pinned words + an event, a small ring per device (concurrent forwards on one
 // ---- device -- several streams or threads -- each get their own slot)
 namespace {
-struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev = nullptr; int device = 0; };
+// (`done`: recorded on the side stream behind this forward's SH -> RGB kernel -- one per slot, so that concurrent forwards
+// on one device do not re-record each other's event)
+struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev = nullptr; hipEvent_t done = nullptr; int device = 0; };
 constexpr int MAX_DEVICES = 32, MAILBOX_RING = 8;
-struct MailboxRing { Mailbox slot[MAILBOX_RING]; std::atomic<unsigned> next{0}; bool ready = false; };
+struct MailboxRing { Mailbox slot[MAILBOX_RING]; std::atomic<unsigned> next{0}; std::atomic<bool> ready{false}; };
 MailboxRing g_mailboxes[MAX_DEVICES];
 std::mutex g_mailbox_mutex;
-std::atomic<uint32_t> g_last_R[MAX_DEVICES]; // tile-list entries of the previous forward on each device (binning-size guess)
+// Binning-size guesses: tile-list entries of the previous forward OF THE SAME KIND on each device.  "Kind" = (P, width,
+// height, tile-row window, sort mode): a small frame that follows a 4K frame (an eval render between training steps, a
+// second rasterizer module) does not inherit the big frame's count.  Direct-mapped, 16 kinds per device; a collision only
+// costs the second allocator call.
+constexpr int GUESS_SLOTS = 16;
+struct SizeGuess { std::atomic<uint64_t> key{0}; std::atomic<uint32_t> R{0}; };
+SizeGuess g_guess[MAX_DEVICES][GUESS_SLOTS];
+uint64_t guess_key(const FrameParams& f)
+{
+    uint64_t k = 0x9E3779B97F4A7C15ull;
+    for (uint64_t v : {(uint64_t)f.P, (uint64_t)f.W, (uint64_t)f.H, (uint64_t)f.ty0, (uint64_t)f.ty1, (uint64_t)f.s.sort_mode,
+                       (uint64_t)(f.s.tile_based_culling * 8 + f.s.rect_bounding * 4 + f.s.tight_opacity_bounding * 2 + (f.s.sort_order == ORDER_PTD_MAX))})
+        k = (k ^ v) * 0xBF58476D1CE4E5B9ull, k ^= k >> 29;
+    return k | 1ull;
+}
 
 // A second stream per device for the SH -> RGB kernel: nothing before the entry gather needs the colours, so the kernel (a
 // pure HBM stream, 70 us at C2) runs BESIDE the host hand-over, duplicate and the tile-bit sort (atomics, small launches and
 // 1.6 TB/s radix passes) instead of in front of them.  It starts behind the mailbox event and is joined back into the
 // caller's stream before the first reader of the colours -- and on every early return, so the caller's buffers are never
 // touched by work the caller's stream does not know about.  STP_SIDE_STREAM=0: everything on the caller's stream.
-struct SideStream { hipStream_t stream = nullptr; hipEvent_t done = nullptr; bool ready = false; };
+struct SideStream { hipStream_t stream = nullptr; std::atomic<bool> ready{false}; };
 SideStream g_side[MAX_DEVICES];
 SideStream* side_stream(int device)
 {
@@ -265,19 +284,18 @@ SideStream* side_stream(int device)
     static const bool off = env && std::strcmp(env, "0") == 0;
     if (off || device < 0 || device >= MAX_DEVICES) return nullptr;
     SideStream& s = g_side[device];
-    if (!s.ready) {
+    if (!s.ready.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(g_mailbox_mutex);
-        if (!s.ready) {
-            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess ||
-                hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            s.ready = true;
+        if (!s.ready.load(std::memory_order_relaxed)) {
+            if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            s.ready.store(true, std::memory_order_release);
         }
     }
     return &s;
 }
 struct SideJoin { // joins the side stream's work into `st` when it goes out of scope, unless done earlier
-    SideStream* s; hipStream_t st; bool pending;
-    hipError_t join() { if (!pending) return hipSuccess; pending = false; return hipStreamWaitEvent(st, s->done, 0); }
+    hipEvent_t done; hipStream_t st; bool pending;
+    hipError_t join() { if (!pending) return hipSuccess; pending = false; return hipStreamWaitEvent(st, done, 0); }
     ~SideJoin() { (void)join(); }
 };
 
@@ -286,19 +304,20 @@ int acquire_mailbox(Mailbox* out)
     int device = 0;
     if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= MAX_DEVICES) return fail(STP_ERR_HIP, "hipGetDevice failed");
     MailboxRing& ring = g_mailboxes[device];
-    if (!ring.ready) {
+    if (!ring.ready.load(std::memory_order_acquire)) {
         std::lock_guard<std::mutex> lock(g_mailbox_mutex);
-        if (!ring.ready) {
+        if (!ring.ready.load(std::memory_order_relaxed)) {
             for (int i = 0; i < MAILBOX_RING; i++) {
                 void* h = nullptr; void* d = nullptr;
                 if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess ||
-                    hipEventCreateWithFlags(&ring.slot[i].ev, hipEventDisableTiming) != hipSuccess)
+                    hipEventCreateWithFlags(&ring.slot[i].ev, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&ring.slot[i].done, hipEventDisableTiming) != hipSuccess)
                     return fail(STP_ERR_HIP, "cannot create the num_rendered mailbox");
                 ring.slot[i].host = static_cast<volatile uint32_t*>(h);
                 ring.slot[i].dev = static_cast<uint32_t*>(d);
                 ring.slot[i].device = device;
             }
-            ring.ready = true;
+            ring.ready.store(true, std::memory_order_release);
         }
     }
     *out = ring.slot[ring.next.fetch_add(1u) % MAILBOX_RING];
@@ -482,21 +501,29 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, st), "mailbox launch");
     STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
     SideStream* const side = side_stream(mb.device);
-    SideJoin colours{side, st, false};
+    SideJoin colours{mb.done, st, false};
     if (side) {
         STP_TRY(hipStreamWaitEvent(side->stream, mb.ev, 0), "side stream wait");
         STP_TRY(launch_sh_color(f, g, radii, side->stream), "SH colour launch");
-        STP_TRY(hipEventRecord(side->done, side->stream), "record colour event");
+        // from here on the side stream works on the caller's buffers: every return path joins it (SideJoin); should the
+        // event that the join waits for fail to record, the side stream is drained on the spot instead
+        if (hipError_t e = hipEventRecord(mb.done, side->stream); e != hipSuccess) {
+            (void)hipStreamSynchronize(side->stream);
+            return fail_hip(e, "record colour event");
+        }
         colours.pending = true;
     } else STP_TRY(launch_sh_color(f, g, radii, st), "SH colour launch");
-    // the binning buffer is requested BEFORE the wait, sized by the previous frame's count on this device (+12.5 %): in
-    // the steady state of training or serving no allocator callback runs between the kernels.  The exact-size request of
-    // the reference follows only when the guess was too small (STP_BINNING=exact: always).
+    // the binning buffer is requested BEFORE the wait, sized by the count of the previous frame of the same kind on this
+    // device (+12.5 %): in the steady state of training or serving no allocator callback runs between the kernels.  The
+    // exact-size request of the reference follows only when the guess was too small (STP_BINNING=exact: always) -- so
+    // binning_alloc may be called TWICE per forward, the second time with the larger size (include/stp_raster.h).
     static const char* const bin_env = std::getenv("STP_BINNING");
     static const bool speculative = !(bin_env && std::strcmp(bin_env, "exact") == 0);
     size_t bin_have = 0;
     char* bin_ptr = nullptr;
-    const uint32_t guess = speculative ? g_last_R[mb.device].load(std::memory_order_relaxed) : 0u;
+    const uint64_t gkey = guess_key(f);
+    SizeGuess& gslot = g_guess[mb.device][(gkey >> 1) % GUESS_SLOTS];
+    const uint32_t guess = (speculative && gslot.key.load(std::memory_order_acquire) == gkey) ? gslot.R.load(std::memory_order_relaxed) : 0u;
     if (guess > 0) {
         carve_binning(nullptr, (size_t)guess + guess / 8, &bin_have);
         bin_ptr = (char*)binning_alloc(binning_user, bin_have);
@@ -507,7 +534,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     f.wild_cov = (host_status[1] & 2u) ? 1 : 0;
     const int R = (int)host_status[0];
-    g_last_R[mb.device].store((uint32_t)R, std::memory_order_relaxed);
+    gslot.R.store((uint32_t)R, std::memory_order_relaxed);
+    gslot.key.store(gkey, std::memory_order_release);
     STP_DEBUG_SYNC("SH colour");
     g_timer.mark(1, st);
 

@@ -212,8 +212,25 @@ __device__ __forceinline__ float exp_blend(float x)
 // Depth of the point of maximum contribution along a view ray (reference stopthepop_common.cuh:44-55).
 // p0 = [S00 S01 S02], p1 = [S11 S12 S22], p2 = Sigma^-1 (mu - cam).  Canonical evaluation order:
 // every dot product is fma(c, z, fma(b, y, a*x)); the reciprocal is the IEEE quotient 1/x.
+#ifndef STP_IEEE_DEPTH
+#define STP_IEEE_DEPTH 0 // 1 (`make IEEE_DEPTH=1`, a TEST-ONLY second library, never the default): the reference's expression with NO
+                         // contraction, every product and sum rounded on its own in the order stopthepop_common.cuh:47-51 writes
+                         // them -- what the -ffp-contract=off build of the reference computes.  With it the product's sort keys,
+                         // tile lists and per-pixel orders are the reference's bit for bit (tests/test_reference_pin.py).
+#endif
 template <bool FAST = false> __device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2, float3 v)
 {
+#if STP_IEEE_DEPTH
+    {
+#pragma clang fp contract(off)
+        const float b0 = (p0.x * v.x + p0.y * v.y) + p0.z * v.z;
+        const float b1 = (p0.y * v.x + p1.x * v.y) + p1.y * v.z;
+        const float b2 = (p0.z * v.x + p1.y * v.y) + p1.z * v.z;
+        const float n = (p2.x * v.x + p2.y * v.y) + p2.z * v.z;
+        const float d = (b0 * v.x + b1 * v.y) + b2 * v.z;
+        return n * rcp_ieee<FAST>(fmaxf(0.00001f, d));
+    }
+#endif
     const float a0 = fmaf(p0.z, v.z, fmaf(p0.y, v.y, p0.x * v.x));
     const float a1 = fmaf(p1.y, v.z, fmaf(p1.x, v.y, p0.y * v.x));
     const float a2 = fmaf(p1.z, v.z, fmaf(p1.y, v.y, p0.z * v.x));
@@ -236,6 +253,17 @@ __device__ __forceinline__ float min_099(float x)
 // every product taking its broadcast operand through DPP: the same operations in the same order, bit for bit.
 template <int I, bool FAST = false> __device__ __forceinline__ float depth_along_ray_quad(float4 c0, float4 c1, float4 c2, float3 v)
 {
+#if STP_IEEE_DEPTH
+    {
+#pragma clang fp contract(off)
+        const float b0 = (quad_mul<I>(c0.x, v.x) + quad_mul<I>(c0.y, v.y)) + quad_mul<I>(c0.z, v.z);
+        const float b1 = (quad_mul<I>(c0.y, v.x) + quad_mul<I>(c1.x, v.y)) + quad_mul<I>(c1.y, v.z);
+        const float b2 = (quad_mul<I>(c0.z, v.x) + quad_mul<I>(c1.y, v.y)) + quad_mul<I>(c1.z, v.z);
+        const float n = (quad_mul<I>(c2.x, v.x) + quad_mul<I>(c2.y, v.y)) + quad_mul<I>(c2.z, v.z);
+        const float d = (b0 * v.x + b1 * v.y) + b2 * v.z;
+        return n * rcp_ieee<FAST>(fmaxf(0.00001f, d));
+    }
+#endif
     const float a0 = quad_fma<I>(c0.z, v.z, quad_fma<I>(c0.y, v.y, quad_mul<I>(c0.x, v.x)));
     const float a1 = quad_fma<I>(c1.y, v.z, quad_fma<I>(c1.x, v.y, quad_mul<I>(c0.y, v.x)));
     const float a2 = quad_fma<I>(c1.z, v.z, quad_fma<I>(c1.y, v.y, quad_mul<I>(c0.z, v.x)));
@@ -248,6 +276,17 @@ template <int I, bool FAST = false> __device__ __forceinline__ float depth_along
 // The same for an entry record (BinningState: A = (S00 S01 S02 S11), B = (S12 S22 q.x q.y), C = (q.z . . .)).
 template <int I, bool FAST = false> __device__ __forceinline__ float depth_along_ray_quad_ent(float4 A, float4 B, float4 C, float3 v)
 {
+#if STP_IEEE_DEPTH
+    {
+#pragma clang fp contract(off)
+        const float b0 = (quad_mul<I>(A.x, v.x) + quad_mul<I>(A.y, v.y)) + quad_mul<I>(A.z, v.z);
+        const float b1 = (quad_mul<I>(A.y, v.x) + quad_mul<I>(A.w, v.y)) + quad_mul<I>(B.x, v.z);
+        const float b2 = (quad_mul<I>(A.z, v.x) + quad_mul<I>(B.x, v.y)) + quad_mul<I>(B.y, v.z);
+        const float n = (quad_mul<I>(B.z, v.x) + quad_mul<I>(B.w, v.y)) + quad_mul<I>(C.x, v.z);
+        const float d = (b0 * v.x + b1 * v.y) + b2 * v.z;
+        return n * rcp_ieee<FAST>(fmaxf(0.00001f, d));
+    }
+#endif
     const float a0 = quad_fma<I>(A.z, v.z, quad_fma<I>(A.y, v.y, quad_mul<I>(A.x, v.x)));
     const float a1 = quad_fma<I>(B.x, v.z, quad_fma<I>(A.w, v.y, quad_mul<I>(A.y, v.x)));
     const float a2 = quad_fma<I>(B.y, v.z, quad_fma<I>(B.x, v.y, quad_mul<I>(A.z, v.x)));

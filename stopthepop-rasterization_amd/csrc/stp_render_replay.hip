@@ -46,6 +46,14 @@ namespace {
 #ifndef STP_REPLAY_OCC
 #define STP_REPLAY_OCC 4
 #endif
+#ifndef STP_REPLAY_COLOR32
+#define STP_REPLAY_COLOR32 0 // 1: the three colour sums as 32-bit fixed point (ds_add_u32 costs half of ds_add_u64, also on shared addresses), the
+                             // six geometric ones stay 64-bit.  MEASURED (round 3, one box, alternating): C2-full 0.947 against 0.928 ms,
+                             // C2-min 1.056 against 1.008, C3 1.87 against 1.72 -- no faster anywhere; kept as a switch for the record.
+#endif
+#if STP_REPLAY_COLOR32 && STP_REPLAY_F64
+#error "STP_REPLAY_F64 keeps all nine sums as doubles"
+#endif
 #ifndef STP_REPLAY_WINDOW
 #define STP_REPLAY_WINDOW 512
 #endif
@@ -63,7 +71,14 @@ __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
 // than the lean loop gains.)
 __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(const RenderArgs a)
 {
+#if STP_REPLAY_COLOR32
+    __shared__ unsigned long long s_acc[6 * WINDOW]; // [term 3..8][position - window start]: the six geometric sums, 64-bit fixed point
+    __shared__ unsigned int s_acc32[3 * WINDOW];     // [term 0..2][position - window start]: the three colour sums, 32-bit fixed point
+    constexpr int ACC64_FIRST = 3;
+#else
     __shared__ unsigned long long s_acc[9 * WINDOW]; // [term][position - window start]
+    constexpr int ACC64_FIRST = 0;
+#endif
     double* const s_accd = reinterpret_cast<double*>(s_acc); // STP_REPLAY_F64: the same sums as doubles (ds_add_f64)
     __shared__ float s_md[4];
 
@@ -79,7 +94,10 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     const int list_len = (int)(range.y - range.x);
     if (list_len <= 0) return;
 
-    for (int i = (int)threadIdx.x; i < 9 * WINDOW; i += 256) s_acc[i] = 0ull;
+    for (int i = (int)threadIdx.x; i < (9 - ACC64_FIRST) * WINDOW; i += 256) s_acc[i] = 0ull;
+#if STP_REPLAY_COLOR32
+    for (int i = (int)threadIdx.x; i < 3 * WINDOW; i += 256) s_acc32[i] = 0u;
+#endif
 
     BwdPixel bp;
     init_bwd_pixel(bp, a, inside, px, py);
@@ -92,9 +110,15 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     __syncthreads(); // (also: the accumulators are zeroed)
     md = fmaxf(fmaxf(s_md[0], s_md[1]), fmaxf(s_md[2], s_md[3]));
     int md_exp = 0;
-    if (md > 0.0f && md < 3.0e38f) (void)frexpf(md, &md_exp);
+    const bool md_ok = md > 0.0f && md < 3.0e38f;
+    if (md_ok) (void)frexpf(md, &md_exp);
     const double fx_scale = ldexp(1.0, 31 - md_exp), fx_inv = ldexp(1.0, md_exp - 31);
-    const float fx_cap = ldexpf(1.0f, min(md_exp + 20, 126));
+    const float fx_cap = (md_ok || md == 0.0f) ? ldexpf(1.0f, min(md_exp + 20, 126)) : 0.0f; // (a tile whose M is not finite: nothing fits, every term goes to memory)
+    // Colour terms: |alpha T dL/dpixel| < M = 2^md_exp by construction (M >= max |dL/dpixel| of the tile), and a lane that the
+    // DPP merge has loaded with its partners' terms carries at most 16 of them: round(t 2^22 / M) fits 27 bits, the sum over
+    // the tile's 256 pixels 31 -- 32-bit LDS adds, which cost half of the 64-bit ones, also where lanes share an address
+    // (tools/lds_atomic_bench.hip: 5.3 / 13.7 against 8.3 / 27.3 cycles at 1 / 4 lanes per address).  Resolution M 2^-23.
+    const float fx_scale32 = ldexpf(1.0f, 22 - max(md_exp, -100)), fx_inv32 = ldexpf(1.0f, max(md_exp, -100) - 22);
 
     // Addressing: wave-uniform bases (SGPR pairs) + one 32-bit byte offset per load, so that the loop's loads are
     // `global_load ... v_off, s[base]` without 64-bit address arithmetic (v_lshl_add_u64 issues at half the rate of a
@@ -192,12 +216,16 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #pragma unroll
             for (int kk = 1; kk < 9; kk++) gmax = fmaxf(gmax, fabsf(g[kk]));
             if (cur_pos >= lo && gmax < fx_cap) { // nine adds, nothing else
+#if STP_REPLAY_COLOR32
 #pragma unroll
-                for (int kk = 0; kk < 9; kk++) {
+                for (int kk = 0; kk < 3; kk++) atomicAdd(&s_acc32[kk * WINDOW + (cur_pos - lo)], (unsigned int)__float2int_rn(g[kk] * fx_scale32));
+#endif
+#pragma unroll
+                for (int kk = ACC64_FIRST; kk < 9; kk++) {
                     // round-to-nearest integer of g*scale through the 1.5*2^52 trick (|g*scale| < 2^51 + margin)
                     const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
                     const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
-                    atomicAdd(&s_acc[kk * WINDOW + (cur_pos - lo)], (unsigned long long)qv);
+                    atomicAdd(&s_acc[(kk - ACC64_FIRST) * WINDOW + (cur_pos - lo)], (unsigned long long)qv);
                 }
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
 #endif
@@ -220,9 +248,19 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                     atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)v);
                 }
 #else
-                const long long v = (long long)s_acc[term * WINDOW + p];
+#if STP_REPLAY_COLOR32
+                if (term < 3) {
+                    const int v32 = (int)s_acc32[term * WINDOW + p];
+                    if (v32 != 0) {
+                        s_acc32[term * WINDOW + p] = 0u;
+                        atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)v32 * fx_inv32);
+                    }
+                    continue;
+                }
+#endif
+                const long long v = (long long)s_acc[(term - ACC64_FIRST) * WINDOW + p];
                 if (v != 0) {
-                    s_acc[term * WINDOW + p] = 0ull;
+                    s_acc[(term - ACC64_FIRST) * WINDOW + p] = 0ull;
                     atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)((double)v * fx_inv));
                 }
 #endif
@@ -242,7 +280,9 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         same_start = __popcll(__ballot(p0 == pmin && n > 0)) >= 40;
     }
 #ifndef STP_REPLAY_HOIST
-#define STP_REPLAY_HOIST 1
+#define STP_REPLAY_HOIST 0 // 1: do not re-zero the terms of a lane that does not blend in a step (round 2).  Its partner in the DPP merge
+                           // multiplies them by zero -- and 0 x Inf is NaN: a lane whose last blend overflowed would poison the sums of
+                           // OTHER Gaussians.  Re-zeroing is nine full-rate v_mov; measured no slower (0.920-0.929 against 0.947 ms).
 #endif
     // (STP_REPLAY_HOIST: the terms of a lane that does not blend in a step are not zeroed -- they keep the lane's last,
     // finite, values; the merge multiplies such a partner by zero and the lane itself adds nothing)

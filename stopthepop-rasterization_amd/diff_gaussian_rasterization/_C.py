@@ -3,10 +3,14 @@
 Mirrors the reference's pybind module of the same name (reference ext.cpp:15-19,
 rasterize_points.cu:43-253): the three functions below take and return exactly the tensors the
 reference's do, in the same order.  PyTorch is used for device memory and the current HIP stream only;
-all compute is in the hand-written HIP library reached through its C ABI (include/stp_raster.h) with
-ctypes -- no torch C++ extension, hence no hipify pass over our sources.
+all compute is in the hand-written HIP library, reached through its C ABI (include/stp_raster.h).
 
-There is NO fallback: if the library is missing or the tensors are not on a GPU, these functions raise.
+The hot functions -- rasterize_gaussians, rasterize_gaussians_backward, mark_visible and the scratch pool -- live in
+the native module `_stp_host` (csrc/host/stp_torch_binding.cpp: a plain C++ torch extension built by g++, no kernels,
+no hipify pass; it allocates through ATen, takes the current stream from c10 and calls the same C ABI).  What stays here
+is cold: the settings POD for the introspection helpers, the backward-mode policy, the stage timer's readers (ctypes).
+
+There is NO fallback: if the library or the native module is missing, or the tensors are not on a GPU, these functions raise.
 """
 from __future__ import annotations
 
@@ -19,6 +23,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_NAME = "libstp_raster.so"
 _lib = None
+_host = None   # the native module _stp_host, bound to the same library file as _lib
 
 
 GRAD_RECORD_FLOATS = 16  # == STP_GRAD_RECORD_FLOATS (include/stp_raster.h): floats per Gaussian in the backward's hand-over buffer
@@ -32,11 +37,18 @@ class StpSettings(ctypes.Structure):
         "load_balancing", "proper_ewa_scaling", "tile_y0", "tile_y1", "record_blend_log", "debug_visualization")]
 
 
-_ALLOC_FN = ctypes.CFUNCTYPE(ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+_lib_override = None
 
 
 def library_path() -> str:
-    return os.environ.get("STP_RASTER_LIB", os.path.join(_HERE, _LIB_NAME))
+    return _lib_override or os.environ.get("STP_RASTER_LIB", os.path.join(_HERE, _LIB_NAME))
+
+
+def use_library(path=None) -> None:
+    """Test hook: the next call loads `path` instead of the product library (None: back to the default).  Used to run the
+    test-only IEEE-depth build (`make IEEE_DEPTH=1`, libstp_raster_ieee.so) against the reference's fixtures."""
+    global _lib, _host, _lib_override
+    _lib, _host, _lib_override = None, None, path
 
 
 def _load():
@@ -50,17 +62,7 @@ def _load():
             f"(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
     L = ctypes.CDLL(path)
     vp, ci, cf = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-    L.stp_forward.restype = ci
-    L.stp_forward.argtypes = [_ALLOC_FN, vp, _ALLOC_FN, vp, _ALLOC_FN, vp, ci, ci, ci, vp, ci, ci,
-                              ctypes.POINTER(StpSettings), vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, cf, cf, ci,
-                              vp, vp, ci, vp]
-    L.stp_backward.restype = ci
-    L.stp_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, ctypes.POINTER(StpSettings), vp, vp, vp, vp, vp, cf, vp, vp,
-                               vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp, vp] + [vp] * 9 + [ci, vp]
-    L.stp_backward_phases.restype = ci
-    L.stp_backward_phases.argtypes = [ci] + L.stp_backward.argtypes
-    L.stp_mark_visible.restype = ci
-    L.stp_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    # (stp_forward / stp_backward_phases / stp_mark_visible are called by the native module _stp_host, not from here)
     L.stp_last_error.restype = ctypes.c_char_p
     L.stp_abi_version.restype = ci
     for name in ("stp_geometry_buffer_size", "stp_binning_buffer_size", "stp_image_buffer_size"):
@@ -78,10 +80,35 @@ def _load():
     L.stp_timing_read.restype = ci
     L.stp_timing_text.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.stp_timing_text.restype = ctypes.c_size_t
-    if L.stp_abi_version() != 4:
+    if L.stp_abi_version() != 5:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L
     return L
+
+
+def _native():
+    """The native module, bound to the library file _load() resolved."""
+    global _host
+    if _host is not None:
+        return _host
+    _load()
+    try:
+        from . import _stp_host
+    except ImportError as ex:
+        raise ImportError(f"the native host binding diff_gaussian_rasterization._stp_host is missing ({ex}): build it with "
+                          f"`python stopthepop-rasterization_amd/csrc/host/build_host.py` (or python -c 'import __graft_entry__ as g; "
+                          f"g.build()').  There is no pure-Python fallback.") from ex
+    _stp_host.load_library(library_path())
+    global _atexit_registered
+    if not _atexit_registered:   # pooled tensors must not outlive the HIP runtime at interpreter shutdown
+        import atexit
+        atexit.register(lambda: _stp_host.clear_scratch_pool(-1))
+        _atexit_registered = True
+    _host = _stp_host
+    return _host
+
+
+_atexit_registered = False
 
 
 def settings_from_dict(d: dict, tile_rows=None) -> StpSettings:
@@ -104,11 +131,93 @@ def settings_from_dict(d: dict, tile_rows=None) -> StpSettings:
     tr = tile_rows if tile_rows is not None else d.get("_tile_rows")
     if tr is not None:
         s.tile_y0, s.tile_y1 = int(tr[0]), int(tr[1])
-    # private key set by the autograd function for training forwards (see __init__._RasterizeGaussians.forward);
-    # STP_BACKWARD=resort in the environment forces the reference-style re-sorting backward everywhere
-    if d.get("_record_blend_log") and os.environ.get("STP_BACKWARD", "replay") != "resort":
+    if _records_log(d):
         s.record_blend_log = 1
     return s
+
+
+# ---- backward-mode policy (blend log: 512 B per pixel of the tile grid held between forward and backward) ----------
+# "replay"  every training forward records the blend log, the backward replays it (fastest; default)
+# "resort"  no log: the backward re-runs the per-pixel resort like the reference's (12 B per pixel held instead of 512)
+# "auto"    record while the logs held by live autograd graphs + the pooled free buffers + the new log stay within
+#           the byte budget, otherwise this forward falls back to "resort" (a trainer that sums K views before one
+#           backward holds K logs)
+# The process-wide default comes from STP_BACKWARD, read ONCE at import; set_backward_mode() changes it at run time and a
+# settings object can override it per call (ExtendedSettings._backward_mode, see __init__.py).
+_BACKWARD_MODES = ("replay", "resort", "auto")
+_backward_mode = os.environ.get("STP_BACKWARD", "replay")
+if _backward_mode not in _BACKWARD_MODES:
+    raise ImportError(f"STP_BACKWARD={_backward_mode!r}: expected one of {_BACKWARD_MODES}")
+_log_budget_bytes = int(float(os.environ.get("STP_LOG_BUDGET_GB", "16")) * (1 << 30))
+_log_live = {}               # device index -> bytes of blend logs held by forwards whose backward has not run yet
+
+
+def set_backward_mode(mode: str, log_budget_bytes=None) -> None:
+    """Process-wide default of the policy above; `log_budget_bytes` (mode "auto") bounds live + pooled + new log bytes per device."""
+    global _backward_mode, _log_budget_bytes
+    if mode not in _BACKWARD_MODES:
+        raise ValueError(f"backward mode {mode!r}: expected one of {_BACKWARD_MODES}")
+    _backward_mode = mode
+    if log_budget_bytes is not None:
+        _log_budget_bytes = int(log_budget_bytes)
+
+
+def backward_mode() -> str:
+    return _backward_mode
+
+
+def blend_log_bytes(width: int, height: int) -> int:
+    """Bytes of the blend log of one forward at this resolution (512 B per pixel of the 16x16 tile grid)."""
+    return ((int(width) + 15) // 16) * ((int(height) + 15) // 16) * 256 * 256 * 2
+
+
+class LogLease:
+    """Accounts one forward's blend log against the device's budget until its backward has run -- or until the autograd
+    graph that holds it is dropped without one (the lease is an attribute of the graph node: it dies with it)."""
+
+    def __init__(self, index: int, nbytes: int):
+        self.index, self.nbytes = index, int(nbytes)
+        _log_live[index] = _log_live.get(index, 0) + self.nbytes
+
+    def release(self) -> None:
+        if self.nbytes:
+            _log_live[self.index] = _log_live.get(self.index, 0) - self.nbytes
+            self.nbytes = 0
+
+    __del__ = release
+
+
+def live_log_bytes(device=None) -> int:
+    return _log_live.get(_device_index(device), 0)
+
+
+def decide_recording(mode, device, width: int, height: int) -> bool:
+    """Does a training forward on `device` record the blend log under policy `mode` (None = the process default)?"""
+    mode = mode or _backward_mode
+    if mode not in _BACKWARD_MODES:
+        raise ValueError(f"backward mode {mode!r}: expected one of {_BACKWARD_MODES}")
+    if mode != "auto":
+        return mode == "replay"
+    idx = _device_index(device)
+    need = blend_log_bytes(width, height)
+    pooled = list(_native().pooled_sizes(idx))
+    reuse = any(need <= n for n in pooled)   # a pooled buffer takes the new log: no new memory
+    return _log_live.get(idx, 0) + sum(pooled) + (0 if reuse else need) <= _log_budget_bytes
+
+
+def _on_device(device):
+    """Context that makes `device` the calling thread's current HIP device (nothing to switch on a box without a GPU)."""
+    import contextlib
+    return torch.cuda.device(_device_index(device)) if torch.cuda.is_available() else contextlib.nullcontext()
+
+
+def _device_index(device) -> int:
+    if device is None:
+        return torch.cuda.current_device()
+    if isinstance(device, int):
+        return device
+    d = torch.device(device)
+    return torch.cuda.current_device() if d.index is None else d.index
 
 
 def _raise_last(rc: int):
@@ -116,135 +225,40 @@ def _raise_last(rc: int):
     raise RuntimeError((msg.decode() if msg else "") or f"libstp_raster error {rc}")
 
 
-def _ptr(t: torch.Tensor):
-    """Device pointer of a contiguous fp32/int32 tensor; empty tensor -> NULL (reference convention:
-    `torch.Tensor([])` marks an absent optional input and its data_ptr is null)."""
-    if t is None or t.numel() == 0:
-        return None
-    return ctypes.c_void_p(t.data_ptr())
-
-
-def _prep(t: torch.Tensor, device) -> torch.Tensor:
-    if t is None or t.numel() == 0:
-        return t
-    if t.device != device:
-        raise RuntimeError(f"expected all tensors on {device}, got one on {t.device}")
-    if t.dtype != torch.float32:
-        raise RuntimeError(f"expected float32 tensor, got {t.dtype}")
-    return t.contiguous()
-
-
-def _stream_ptr(device) -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-
-
-# The binning buffer (tile lists + list-ordered entry records, ~100 B per entry) and the training forward's image
-# buffer are large.  The latter carries the blend log (512 B per pixel of the tile grid, 1.07 GB at 1080p).
-# Cycling a block of that size through torch's caching allocator every step invites splitting: smaller requests
-# carve pieces off the free block, the next forward finds no 2 GB hole and the allocator falls back to hipMalloc
-# (tens of ms per step, reserved memory growing by 2 GB a step -- observed on MI355X).  Buffers of this class are
-# therefore kept on a small free list of our own: handed out by the forward, handed back by the backward.
-_BIG_BYTES = 256 << 20
-_BIG_STEP = 64 << 20
-_BIG_KEEP = 4                # free buffers kept per device (see also set_scratch_pool_limit)
-_big_max_bytes = None        # optional cap on the bytes the free list may hold per device
-_big_free = {}               # device index -> [(tensor, event recorded on the releasing stream), ...]
-_big_generation = {}         # data_ptr -> how many times the buffer at this address was handed out
-
-
+# ---- scratch pool (csrc/host/stp_torch_binding.cpp: buffers of >= 256 MiB -- tile lists with their entry records, image
+# ---- state with the blend log -- are kept on a free list per device instead of cycling through torch's caching allocator)
 def clear_scratch_pool(device=None) -> int:
     """Drops the pooled scratch buffers (tile lists / blend logs waiting for reuse) of `device` (all devices when None) so
     that torch.cuda.empty_cache() can hand their memory back; returns the number of bytes released.  Buffers that a live
     autograd graph still holds are not affected."""
-    freed = 0
-    for d in list(_big_free) if device is None else [torch.device(device).index if not isinstance(device, int) else device]:
-        for t, _ in _big_free.pop(d, []):
-            freed += t.numel()
-    return freed
+    return int(_native().clear_scratch_pool(-1 if device is None else _device_index(device)))   # ('cuda' = the current device)
 
 
 def set_scratch_pool_limit(max_buffers: int = 4, max_bytes=None) -> None:
     """Bounds the free list: at most `max_buffers` buffers and (optionally) `max_bytes` bytes per device stay pooled."""
-    global _BIG_KEEP, _big_max_bytes
-    _BIG_KEEP, _big_max_bytes = int(max_buffers), (None if max_bytes is None else int(max_bytes))
-
-
-class _Resizer:
-    """The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request.  The library may
-    call it twice per forward (a size guess before the num_rendered hand-over, the exact size afterwards if the guess
-    was short): a request the current buffer already covers returns the same pointer."""
-
-    def __init__(self, device, pooled=False):
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.pooled = pooled
-        self.from_pool = False
-        self.cb = _ALLOC_FN(self._alloc)
-
-    def _alloc(self, _user, nbytes):
-        try:
-            nbytes = int(nbytes)
-            if nbytes <= self.tensor.numel() and nbytes > 0:
-                return self.tensor.data_ptr()
-            if self.pooled and nbytes >= _BIG_BYTES:
-                if self.from_pool:       # the guess was too small: the buffer goes back, a larger one comes
-                    _put_back(self.tensor)
-                # capacity in steps of 64 MiB, so that a buffer whose size follows the number of tile-list entries
-                # (it changes a little from view to view) finds its predecessor on the free list
-                cap = (nbytes + _BIG_STEP - 1) // _BIG_STEP * _BIG_STEP
-                free = _big_free.setdefault(self.tensor.device.index, [])
-                fits = [i for i, (t, _) in enumerate(free) if nbytes <= t.numel() <= cap + cap // 4]
-                hit = min(fits, key=lambda i: free[i][0].numel()) if fits else None
-                if hit is not None:
-                    self.tensor, ev = free.pop(hit)
-                    if ev is not None:   # the releasing stream's kernels may still be reading it: order this stream behind them
-                        torch.cuda.current_stream(self.tensor.device).wait_event(ev)
-                else:
-                    self.tensor = torch.empty(cap, dtype=torch.uint8, device=self.tensor.device)
-                self.from_pool = True
-                ptr = self.tensor.data_ptr()
-                _big_generation[ptr] = _big_generation.get(ptr, 0) + 1
-                return ptr
-            self.tensor.resize_(nbytes)
-            return self.tensor.data_ptr() if nbytes else 0
-        except Exception:  # surfaces as STP_ERR_ALLOC on the C side
-            return 0
+    _native().set_scratch_pool_limit(int(max_buffers), -1 if max_bytes is None else int(max_bytes))
 
 
 def scratch_generation(buf: torch.Tensor) -> int:
     """Token the autograd function keeps with a pooled buffer (0 for ordinary ones); see check_scratch."""
-    return _big_generation.get(buf.data_ptr(), 0) if buf.numel() >= _BIG_BYTES else 0
+    return int(_native().scratch_generation(buf))
 
 
 def check_scratch(buf: torch.Tensor, generation: int) -> None:
     """A second backward through a retained graph after a later forward reused the buffer must not read that
     forward's blend log: fail loudly instead."""
-    if generation and _big_generation.get(buf.data_ptr(), 0) != generation:
-        raise RuntimeError("a scratch buffer of this forward (tile lists / blend log) was recycled by a later forward "
-                           "pass; run the forward again before this backward")
-
-
-def _put_back(buf: torch.Tensor) -> None:
-    free = _big_free.setdefault(buf.device.index, [])
-    if any(t.data_ptr() == buf.data_ptr() for t, _ in free):
-        return
-    ev = torch.cuda.Event()
-    ev.record(torch.cuda.current_stream(buf.device))
-    free.append((buf, ev))
-    while len(free) > _BIG_KEEP or (_big_max_bytes is not None and len(free) > 1 and sum(t.numel() for t, _ in free) > _big_max_bytes):
-        free.pop(0)
+    _native().check_scratch(buf, int(generation))
 
 
 def release_scratch(buf: torch.Tensor) -> None:
     """Hand a pooled buffer back after the backward that consumed it (reuse is ordered behind the releasing stream)."""
-    if buf.numel() < _BIG_BYTES or not buf.is_cuda:
-        return
-    _put_back(buf)
+    _native().release_scratch(buf)
 
 
-def _require_gpu(means3D: torch.Tensor):
-    if not means3D.is_cuda:
-        raise RuntimeError("diff_gaussian_rasterization (MI355X build) needs tensors on a GPU device; "
-                           "there is no CPU path in the product")
+def _records_log(d: dict) -> bool:
+    # private key set by the autograd function for training forwards (see __init__._RasterizeGaussians.forward, which
+    # applies the backward-mode policy above); mode "resort" forces the reference-style re-sorting backward everywhere
+    return bool(d.get("_record_blend_log")) and d.get("_backward_mode", _backward_mode) != "resort"
 
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -253,41 +267,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         ) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """== RasterizeGaussiansCUDA (reference rasterize_points.cu:43-138).
     Returns (num_rendered, out_color (3,H,W), radii (P,) int32, geomBuffer, binningBuffer, imgBuffer)."""
-    L = _load()
-    if means3D.dim() != 2 or means3D.size(1) != 3:
+    if means3D.dim() != 2 or means3D.size(1) != 3:   # (the reference's first check, rasterize_points.cu:69-71)
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
-    _require_gpu(means3D)
-    dev = means3D.device
-    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
-    # the render kernels write every pixel of the tile rows they cover and preprocess writes every Gaussian's radius:
-    # zero-filled outputs are only needed when nothing runs (P == 0) or when a tile-row window leaves rows untouched
-    windowed = settings_dict.get("_tile_rows") is not None
-    make = torch.zeros if (P == 0 or windowed) else torch.empty
-    out_color = make((3, H, W), dtype=torch.float32, device=dev)
-    radii = make((P,), dtype=torch.int32, device=dev)
-    geom, binning, img = _Resizer(dev), _Resizer(dev, pooled=True), _Resizer(dev, pooled=True)
-    rendered = 0
-    if P != 0:
-        M = int(sh.size(1)) if sh.numel() != 0 else 0
-        s = settings_from_dict(settings_dict)
-        if render_depth:  # DebugVisualization::Depth (reference rasterize_points.cu:104-107); no log: it has no backward
-            s.debug_visualization = 1
-            s.record_blend_log = 0
-        t = [_prep(x, dev) for x in (background, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp,
-                                     viewmatrix, projmatrix, inv_viewprojmatrix, campos)]
-        bg_, m3_, sh_, col_, op_, sc_, ro_, c3_, vm_, pm_, inv_, cam_ = t
-        with torch.cuda.device(dev):
-            rc = L.stp_forward(geom.cb, None, binning.cb, None, img.cb, None, P, int(degree), M, _ptr(bg_), W, H,
-                               ctypes.byref(s), _ptr(m3_), _ptr(sh_), _ptr(col_), _ptr(op_), _ptr(sc_),
-                               ctypes.c_float(scale_modifier), _ptr(ro_), _ptr(c3_), _ptr(vm_), _ptr(pm_), _ptr(inv_),
-                               _ptr(cam_), ctypes.c_float(tan_fovx), ctypes.c_float(tan_fovy), int(bool(prefiltered)),
-                               _ptr(out_color), _ptr(radii), int(bool(debug)), _stream_ptr(dev))
-        for r in (geom, binning, img):
-            r.cb = None  # the callback object refers to its resizer: a cycle that would keep the buffers alive until a gc run
-        if rc < 0:
-            _raise_last(rc)
-        rendered = rc
-    return rendered, out_color, radii, geom.tensor, binning.tensor, img.tensor
+    return (_host or _native()).rasterize_gaussians(
+        background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+        inv_viewprojmatrix, tan_fovx, tan_fovy, int(image_height), int(image_width), sh, int(degree), campos, bool(prefiltered),
+        settings_dict, bool(render_depth), bool(debug), _records_log(settings_dict))
 
 
 def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, scales, rotations, scale_modifier,
@@ -300,61 +285,16 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
     Extension for tile-row sharding (not in the reference): phases=1 runs only the render half and
     returns its per-Gaussian partial sums as the library's (P,16) gradient records (stp_raster.h);
     phases=2 takes the records (after the caller's all-reduce) as `partial` and runs the preprocess half."""
-    L = _load()
-    _require_gpu(means3D)
-    dev = means3D.device
-    P = int(means3D.size(0))
-    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
-    M = int(sh.size(1)) if sh.numel() != 0 else 0
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)
-    records = partial if partial is not None else z(P, GRAD_RECORD_FLOATS)
-    if records.shape != (P, GRAD_RECORD_FLOATS) or records.dtype != torch.float32 or not records.is_contiguous():
-        raise ValueError("partial must be a contiguous float32 (P,%d) tensor" % GRAD_RECORD_FLOATS)
-    if phases & 2:
-        # the per-Gaussian half writes every row of its outputs (zeros for invisible Gaussians): no zero-fill needed,
-        # except for the scale/rotation gradients when a precomputed covariance is used (then they are not touched)
-        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        zs = e if scales.numel() != 0 else z
-        dL_dmeans2D, dL_dcolors, dL_dopacity = e(P, 3), e(P, 3), e(P, 1)
-        dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations = e(P, 3), e(P, 6), e(P, M, 3), zs(P, 3), zs(P, 4)
-    else:
-        dL_dmeans2D = dL_dcolors = dL_dopacity = None
-        dL_dmeans3D = dL_dcov3D = dL_dsh = dL_dscales = dL_drotations = None
-    s = settings_from_dict(settings_dict)
-    if P != 0:
-        t = [_prep(x, dev) for x in (background, means3D, sh, colors, opacities, scales, rotations, cov3D_precomp,
-                                     viewmatrix, projmatrix, inv_viewprojmatrix, campos, pixel_colors, dL_dout_color)]
-        bg_, m3_, sh_, col_, op_, sc_, ro_, c3_, vm_, pm_, inv_, cam_, pix_, dl_ = t
-        radii_ = radii.contiguous()
-        with torch.cuda.device(dev):
-            rc = L.stp_backward_phases(int(phases), P, int(degree), M, int(R), _ptr(bg_), W, H, ctypes.byref(s), _ptr(m3_),
-                                       _ptr(sh_), _ptr(op_), _ptr(col_), _ptr(sc_), ctypes.c_float(scale_modifier), _ptr(ro_),
-                                       _ptr(c3_), _ptr(vm_), _ptr(pm_), _ptr(inv_), _ptr(cam_), ctypes.c_float(tan_fovx),
-                                       ctypes.c_float(tan_fovy), _ptr(pix_), _ptr(radii_), _ptr(geomBuffer),
-                                       _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dl_), _ptr(dL_dmeans2D), _ptr(records),
-                                       _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D), _ptr(dL_dsh),
-                                       _ptr(dL_dscales), _ptr(dL_drotations), int(bool(debug)), _stream_ptr(dev))
-        if rc < 0:
-            _raise_last(rc)
-    if phases == 1:
-        return records
-    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
+    out = (_host or _native()).rasterize_gaussians_backward(
+        background, means3D, radii, opacities, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
+        inv_viewprojmatrix, tan_fovx, tan_fovy, pixel_colors, dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer,
+        imageBuffer, settings_dict, bool(debug), _records_log(settings_dict), int(phases), partial)
+    return out[0] if phases == 1 else tuple(out)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
     """== markVisible (reference rasterize_points.cu:234-253)."""
-    L = _load()
-    _require_gpu(means3D)
-    dev = means3D.device
-    P = int(means3D.size(0))
-    present = torch.zeros((P,), dtype=torch.bool, device=dev)
-    if P != 0:
-        m3_, vm_, pm_ = (_prep(x, dev) for x in (means3D, viewmatrix, projmatrix))
-        with torch.cuda.device(dev):
-            rc = L.stp_mark_visible(P, _ptr(m3_), _ptr(vm_), _ptr(pm_), ctypes.c_void_p(present.data_ptr()), _stream_ptr(dev))
-        if rc < 0:
-            _raise_last(rc)
-    return present
+    return (_host or _native()).mark_visible(means3D, viewmatrix, projmatrix)
 
 
 # ---- introspection helpers (tests / bench; not part of the reference surface) -----------------------
@@ -367,10 +307,11 @@ _IMG_TYPES = {"final_T": torch.float32, "n_contrib": torch.int32, "ranges": torc
               "blend_log": torch.int16}  # the last two exist only in a buffer of a recording forward
 
 
-def timing_text() -> str:
-    """The reference's `timings_text` (what its viewer displays), from the stages measured since timing_enable(True)."""
+def timing_text(device=None) -> str:
+    """The reference's `timings_text` (what its viewer displays), from the stages measured on `device` since timing_enable(True)."""
     buf = ctypes.create_string_buffer(512)
-    _load().stp_timing_text(buf, 512)
+    with _on_device(device):
+        _load().stp_timing_text(buf, 512)
     return buf.value.decode()
 
 
@@ -405,9 +346,13 @@ def timing_enable(flag: bool) -> None:
     _load().stp_timing_enable(int(bool(flag)))
 
 
-def timing_read():
-    """Milliseconds of the last call's stages: Preprocess, Duplicate, Sort, Render, BwdRender, BwdPreprocess."""
+def timing_read(device=None):
+    """Mean milliseconds of the stages timed on `device` (default: the current one) since timing_enable(True): Preprocess,
+    Duplicate, Sort, Render, BwdRender, BwdPreprocess; -1 = not measured.  The library keeps one timer per device."""
     arr = (ctypes.c_float * 6)()
-    _load().stp_timing_read(arr)
+    with _on_device(device):
+        rc = _load().stp_timing_read(arr)
+    if rc < 0:
+        _raise_last(rc)
     names = ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess")
     return {n: float(v) for n, v in zip(names, arr)}

@@ -49,12 +49,22 @@ class _RasterizeGaussians(torch.autograd.Function):
                 raster_settings):
         rs = raster_settings
         sdict = rs.settings.to_dict()
+        ctx.log_lease = None
         if any(ctx.needs_input_grad) and not rs.render_depth:
-            # a backward can follow: let the hierarchical forward record each pixel's blend order so that the
-            # backward replays it instead of re-sorting (extension of ours; ignored by the other sort modes).
+            # a backward can follow: let the hierarchical / k-buffer forward record each pixel's blend order so that the
+            # backward replays it instead of re-sorting (extension of ours; ignored by the other sort modes) -- unless the
+            # backward-mode policy says otherwise (_C.set_backward_mode / STP_BACKWARD / settings._backward_mode: "resort",
+            # or "auto" with the device's blend-log budget used up by forwards that still wait for their backward).
             # Not with render_depth: the depth-visualisation forward records no log, and a backward through it
             # (meaningless in the reference too, but memory-safe there) must take the re-sorting path.
-            sdict["_record_blend_log"] = True
+            mode = sdict.get("_backward_mode")
+            uses_log = int(sdict["sort_settings"]["sort_mode"]) in (2, 3)
+            if uses_log and means3D.is_cuda and means3D.size(0) != 0 and _C.decide_recording(mode, means3D.device, rs.image_width, rs.image_height):
+                sdict["_record_blend_log"] = True
+                sdict["_backward_mode"] = "replay"
+                ctx.log_lease = _C.LogLease(_C._device_index(means3D.device), _C.blend_log_bytes(rs.image_width, rs.image_height))
+            else:
+                sdict["_backward_mode"] = "resort"
         ctx.settings_dict = sdict
         # positional layout of _C.rasterize_gaussians (22 arguments)
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -106,6 +116,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
         _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)  # the blend log goes back to the library's free list
+        if ctx.log_lease is not None:
+            ctx.log_lease.release()
         # one gradient per forward input, in forward's order
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
                 grad_cov3Ds_precomp, None)
@@ -183,7 +195,10 @@ class ExtendedSettings(_Settable):
                                   "sort_mode": as_int(ss.sort_mode), "sort_order": as_int(ss.sort_order)},
                 "culling_settings": {"rect_bounding": cs.rect_bounding, "tight_opacity_bounding": cs.tight_opacity_bounding,
                                      "tile_based_culling": cs.tile_based_culling, "hierarchical_4x4_culling": cs.hierarchical_4x4_culling},
-                "load_balancing": self.load_balancing, "proper_ewa_scaling": self.proper_ewa_scaling}
+                "load_balancing": self.load_balancing, "proper_ewa_scaling": self.proper_ewa_scaling,
+                # (extension, not a dataclass field: `settings._backward_mode = "replay" | "resort" | "auto"` overrides the
+                # process-wide backward-mode policy of _C.set_backward_mode for the calls made with this settings object)
+                **({"_backward_mode": self._backward_mode} if getattr(self, "_backward_mode", None) else {})}
 
     def to_json(self):
         return json.dumps(self.to_dict())

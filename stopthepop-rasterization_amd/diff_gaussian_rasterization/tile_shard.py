@@ -179,8 +179,16 @@ class _ShardedRasterize(torch.autograd.Function):
         y0, y1 = parts[rank]
         n_rows = tile_rows(rs.image_height)
         sdict["_tile_rows"] = (y0, y1) if y1 > y0 else (n_rows, n_rows)   # (an empty block; (0, 0) would mean "all rows" to the library)
-        if any(ctx.needs_input_grad) and not rs.render_depth:
-            sdict["_record_blend_log"] = True
+        ctx.log_lease = None
+        if any(ctx.needs_input_grad) and not rs.render_depth:   # the backward-mode policy of the unsharded autograd function (__init__.py)
+            uses_log = int(sdict["sort_settings"]["sort_mode"]) in (2, 3)
+            if uses_log and means3D.is_cuda and means3D.size(0) != 0 and \
+                    _C.decide_recording(sdict.get("_backward_mode"), means3D.device, rs.image_width, rs.image_height):
+                sdict["_record_blend_log"] = True
+                sdict["_backward_mode"] = "replay"
+                ctx.log_lease = _C.LogLease(_C._device_index(means3D.device), _C.blend_log_bytes(rs.image_width, rs.image_height))
+            else:
+                sdict["_backward_mode"] = "resort"
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
                 rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, sdict, rs.render_depth, rs.debug)
@@ -191,7 +199,12 @@ class _ShardedRasterize(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
         if shard_state is not None:   # per-row work of this frame (own rows) for the next frame's partition
-            shard_state["pending"] = (imgBuffer, rs.image_width, rs.image_height)
+            # reduced HERE, while the image buffer is certainly this frame's: the backward hands the buffer back to the scratch
+            # pool, and another rasterizer on the device (an eval render, a second sharded module) may have reused it by the
+            # time the next frame is partitioned -- only the small per-row tensor is kept
+            gx = (rs.image_width + 15) // 16
+            r = _C.image_array(imgBuffer, rs.image_width, rs.image_height, "ranges").reshape(-1, 2)[: gx * n_rows].to(torch.int64)
+            shard_state["pending"] = (r[:, 1] - r[:, 0]).reshape(n_rows, gx).sum(dim=1).to(torch.float32)
         full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
         ctx.mark_non_differentiable(radii)
         # every rank returns a (3,H,W) tensor: the assembled frame where it is available, else the local strip image
@@ -221,6 +234,8 @@ class _ShardedRasterize(torch.autograd.Function):
         records[:, :RECORD_USED] = used
         out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
         _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)
+        if ctx.log_lease is not None:
+            ctx.log_lease.release()
         (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
          grad_rotations) = out
         return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
@@ -249,11 +264,8 @@ class TileRowShardedRasterizer(torch.nn.Module):
     def _repartition(self):
         """per-row entry counts of the last frame (own rows) -> summed over ranks -> balanced_partition"""
         dist, rank, world, to_all = self._comm
-        img, W, H = self.state["pending"]
+        cost = self.state["pending"]   # (n_rows,) tile-list entries per tile row of the last frame, this rank's rows (reduced in forward)
         self.state["pending"] = None
-        gx = (W + 15) // 16
-        r = _C.image_array(img, W, H, "ranges").reshape(-1, 2)[: gx * self.n_rows].to(torch.int64)
-        cost = (r[:, 1] - r[:, 0]).reshape(self.n_rows, gx).sum(dim=1).to(torch.float32)
         if _host_staged(dist) and cost.is_cuda:
             host = cost.cpu()
             dist.all_reduce(host)

@@ -30,7 +30,10 @@ def max_abs(a, b):
 def ext_settings(d):
     """dict -> diff_gaussian_rasterization.ExtendedSettings"""
     import diff_gaussian_rasterization as dgr
-    return dgr.ExtendedSettings.from_dict(d)
+    es = dgr.ExtendedSettings.from_dict(d)
+    if d.get("_backward_mode"):   # (our per-call extension rides on the settings object, see ExtendedSettings.to_dict)
+        es._backward_mode = d["_backward_mode"]
+    return es
 
 
 class GpuRun:

@@ -106,9 +106,23 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared <= exported
 
 
+def test_native_host_binding_loads_and_binds_the_c_abi():
+    """The native torch binding (csrc/host/stp_torch_binding.cpp) imports on a box without a GPU, binds the library file _C resolved
+    (run-time dlopen: STP_RASTER_LIB / _C.use_library keep working) and exports the reference's three functions + the pool surface."""
+    h = _C._native()
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "scratch_generation", "check_scratch", "release_scratch",
+                 "clear_scratch_pool", "set_scratch_pool_limit", "pooled_sizes", "load_library"):
+        assert callable(getattr(h, name)), name
+    assert h.load_library(_C.library_path()) == 5
+    assert _C.clear_scratch_pool() == 0 and list(h.pooled_sizes(0)) == []
+    with pytest.raises(RuntimeError, match="cannot load"):
+        h.load_library("/nonexistent/libstp_raster.so")
+    assert h.load_library(_C.library_path()) == 5   # (a failed load leaves the bound library in place)
+
+
 def test_c_abi_size_and_layout_queries_without_gpu():
     L = _C._load()
-    assert L.stp_abi_version() == 4
+    assert L.stp_abi_version() == 5
     s = _C.settings_from_dict(dgr.ExtendedSettings().to_dict())
     small, big = L.stp_geometry_buffer_size(1000, ctypes.byref(s)), L.stp_geometry_buffer_size(2000, ctypes.byref(s))
     assert 0 < small < big

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import FULL_STP, GpuRun, max_abs, oracle_run, psnr, settings_dict
+from helpers import FULL_STP, GpuRun, ext_settings, max_abs, oracle_run, psnr, settings_dict
 from diff_gaussian_rasterization import scenes
 
 pytestmark = pytest.mark.gpu
@@ -254,17 +254,80 @@ def test_blend_log_mixed_tiles():
     assert flags.any() and not flags.all(), flags
 
 
-def test_resorting_backward_still_selectable(monkeypatch):
-    """STP_BACKWARD=resort: no log is recorded, the backward re-runs the resort (the reference's scheme)."""
-    monkeypatch.setenv("STP_BACKWARD", "resort")
+def test_resorting_backward_still_selectable():
+    """Backward mode "resort" (process-wide: _C.set_backward_mode / STP_BACKWARD at import; per call: settings._backward_mode):
+    no log is recorded, the backward re-runs the resort (the reference's scheme)."""
+    from diff_gaussian_rasterization import _C
     sc = scenes.make_scene(**DENSE)
-    g_resort, _ = check_against_oracle(sc, settings_dict(**FULL_STP))
-    monkeypatch.delenv("STP_BACKWARD")
-    g_replay = GpuRun(sc, settings_dict(**FULL_STP))
+    sd = settings_dict(**FULL_STP)
+    W, H = sc.W, sc.H
+    log_bytes = _C.blend_log_bytes(W, H)
+    _C.set_backward_mode("resort")
+    try:
+        g_resort, _ = check_against_oracle(sc, sd)
+    finally:
+        _C.set_backward_mode("replay")
+    g_replay = GpuRun(sc, sd)
+    assert g_replay.img.numel() >= g_resort.img.numel() + log_bytes  # the resorting run really carried no log
     assert np.array_equal(g_resort.color, g_replay.color)  # recording must not change the image
     for k in GRAD_KEYS:
         if g_resort.grads.get(k) is not None:
             assert _rel(g_replay.grads[k], g_resort.grads[k]) < 1e-5, k
+    # the same choice per call, through the settings object
+    g_call = GpuRun(sc, {**sd, "_backward_mode": "resort"})
+    assert g_call.img.numel() == g_resort.img.numel()
+    for k in GRAD_KEYS:
+        if g_resort.grads.get(k) is not None:
+            assert _rel(g_call.grads[k], g_resort.grads[k]) < 1e-5, k   # (the re-sorting backward sums with fp32 atomics: not bit-reproducible)
+
+
+def test_backward_mode_auto_holds_eight_1080p_forwards_within_a_4GB_log_budget():
+    """A trainer that sums K views before ONE backward holds K blend logs (1.07 GB each at 1080p).  Mode "auto" records
+    while live + pooled + new log bytes fit the budget and lets the remaining forwards take the re-sorting backward:
+    eight un-backpropagated 1080p forwards under a 4 GB budget keep three logs, and the gradients of the summed loss equal
+    those of eight replayed forwards."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C
+    K = 8
+    sc = scenes.make_scene(P=60000, W=1920, H=1080, sigma_min=2.0, sigma_max=12.0, seed=71, camera="orbit")
+    dev = torch.device("cuda:0")
+    t = lambda a, rg=False: torch.tensor(a, device=dev).requires_grad_(rg)
+    es = ext_settings(settings_dict(**FULL_STP))
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=t(sc.bg), scale_modifier=1.0,
+        viewmatrix=t(sc.viewmatrix), projmatrix=t(sc.projmatrix), inv_viewprojmatrix=t(sc.inv_viewprojmatrix), sh_degree=sc.sh_degree,
+        campos=t(sc.campos), prefiltered=False, settings=es, render_depth=False, debug=False)
+    rast = dgr.GaussianRasterizer(rs)
+    w = t(sc.dL_dout)
+    log_bytes = _C.blend_log_bytes(sc.W, sc.H)
+    assert 1.0e9 < log_bytes < 1.2e9
+
+    def run(mode, budget):
+        _C.clear_scratch_pool(dev)
+        _C.set_backward_mode(mode, log_budget_bytes=budget)
+        try:
+            leaves = [t(sc.means3D, True), torch.zeros(sc.P, 3, device=dev, requires_grad=True), t(sc.opacities, True), t(sc.shs, True),
+                      t(sc.scales, True), t(sc.rotations, True)]
+            m3, m2, op, sh, scl, rot = leaves
+            total, recorded, peak = 0.0, 0, 0
+            for i in range(K):
+                color, _ = rast(m3, m2, op, shs=sh, scales=scl, rotations=rot)
+                recorded += int(color.grad_fn.saved_tensors[11].numel() >= log_bytes)
+                total = total + (color * w).sum() * (1.0 + 0.125 * i)
+                peak = max(peak, _C.live_log_bytes(dev))
+            total.backward()
+            assert _C.live_log_bytes(dev) == 0   # every lease went back with its backward
+            return [x.grad.detach().cpu().numpy() for x in leaves], recorded, peak
+        finally:
+            _C.set_backward_mode("replay", log_budget_bytes=16 << 30)
+            _C.clear_scratch_pool(dev)
+
+    g_auto, n_auto, peak_auto = run("auto", 4_000_000_000)
+    assert n_auto == 3 and peak_auto <= 4_000_000_000, (n_auto, peak_auto)   # 3 x 1.07 GB fit 4 GB, the fourth does not
+    g_replay, n_replay, _ = run("replay", None)
+    assert n_replay == K
+    for a, b in zip(g_auto, g_replay):
+        assert _rel(a, b) < 2e-5
 
 
 def test_forward_without_grad_records_nothing():

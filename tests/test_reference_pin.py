@@ -96,6 +96,52 @@ def test_product_against_reference_fixtures(path):
                                    z["color"], grads, c3=c3)
 
 
+# ---- the one tolerance-only link, closed: the TEST-ONLY build of the library whose depth keys are the reference's uncontracted
+# ---- expression (make IEEE_DEPTH=1 -> libstp_raster_ieee.so; the product evaluates depthAlongRay with fused multiply-adds in one
+# ---- canonical order, which moves keys by an ulp now and then and swaps neighbours in the lists).  Against the reference's IEEE
+# ---- build (hipify-perl + adapter header, hipcc -ffp-contract=off; not nvcc) this library must reproduce keys, lists and ranges BIT
+# ---- FOR BIT in every per-tile-depth / k-buffer / hierarchical case, the image to 2e-6 and the gradients to 1e-4.
+IEEE_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "stopthepop-rasterization_amd", "diff_gaussian_rasterization", "libstp_raster_ieee.so")
+
+
+@pytest.fixture
+def ieee_depth_library():
+    from diff_gaussian_rasterization import _C
+    if not os.path.exists(IEEE_LIB):
+        pytest.skip("libstp_raster_ieee.so not built (make -C stopthepop-rasterization_amd/csrc IEEE_DEPTH=1)")
+    _C.use_library(os.path.abspath(IEEE_LIB))
+    try:
+        yield
+    finally:
+        _C.use_library(None)
+
+
+def _sorted_by_depth_along_ray(sd):
+    return sd["sort_settings"]["sort_mode"] != 0 or sd["sort_settings"]["sort_order"] >= 2
+
+
+@pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
+def test_ieee_depth_build_is_bit_exact_with_the_reference_fixtures(path, ieee_depth_library):
+    z, sc, sd, c3 = load_case(path)
+    if bool(z["render_depth"]) or not _sorted_by_depth_along_ray(sd) or int(z["num_rendered"]) == 0:
+        pytest.skip("no depthAlongRay in this case")
+    g = GpuRun(sc, sd, backward=True, cov3D_precomp=c3)
+    assert g.num_rendered == int(z["num_rendered"]) and np.array_equal(g.radii, z["radii"])
+    tight = sd["culling_settings"]["tight_opacity_bounding"]
+    if not tight:   # (tight_opacity_bounding: rects2D within 2 ulp of the reference's, one logf -- documented in DESIGN.md section 5)
+        assert np.array_equal(g.binning_array("keys"), z["keys"])
+        assert np.array_equal(g.binning_array("point_list"), z["point_list"])
+    assert np.array_equal(g.image_array("ranges").view(np.uint32).reshape(-1)[:z["ranges"].size], z["ranges"])
+    assert max_abs(g.color, z["color"]) <= 2e-6
+    for k in PRODUCT_GRADS:
+        a, b = g.grads.get(k), z["grad_" + k] if "grad_" + k in z.files else None
+        if a is None or b is None or b.size == 0:
+            continue
+        if k == "dL_dmeans2D":
+            a, b = a[:, :2], b[:, :2]
+        assert _rel(a, b) <= 1e-4, k
+
+
 LIVE = pytest.mark.skipif(not (ref.available("ieee") and ref.available("fast")),
                           reason="oracle/_ref not built (oracle/ref_build/build_ref.sh needs /root/reference)")
 
@@ -124,6 +170,31 @@ def test_product_against_the_live_reference(name, sd, variant):
             return
     compare_product_with_reference(g, sc, sd, rf.num_rendered, rf.radii, state, rf.array("keys"), rf.array("point_list"),
                                    rf.array("ranges"), rf.color, rg, strict_state=strict)
+
+
+@LIVE
+@pytest.mark.parametrize("name,sd", [
+    ("kbuffer16", settings_dict(2, per_pixel=16)), ("hier", settings_dict(3)), ("hier_cull_h8_m12", settings_dict(3, per_pixel=8, tile_2x2=12, h44=True)),
+    ("ptd_max", settings_dict(0, order=3)), ("full_stp", settings_dict(**{**FULL_STP, "tight": False}))])
+def test_ieee_depth_build_is_bit_exact_with_the_live_reference(name, sd, ieee_depth_library):
+    """Fresh seed, dense scene (~700 entries per tile): the IEEE-depth build of the library against the reference's IEEE build, live."""
+    sc = scenes.make_scene(P=6000, W=96, H=80, sigma_min=2.0, sigma_max=14.0, seed=79, camera="orbit")
+    rf = ref.forward_scene(sc, sd, variant="ieee")
+    rg = rf.backward(sc.dL_dout)
+    g = GpuRun(sc, sd, backward=True)
+    assert g.num_rendered == rf.num_rendered and np.array_equal(g.radii, rf.radii)
+    assert np.array_equal(g.binning_array("keys"), rf.array("keys"))
+    assert np.array_equal(g.binning_array("point_list"), rf.array("point_list"))
+    r_ranges = rf.array("ranges")
+    assert np.array_equal(g.image_array("ranges").view(np.uint32).reshape(-1)[:r_ranges.size], r_ranges)
+    assert max_abs(g.color, rf.color) <= 2e-6
+    for k in PRODUCT_GRADS:
+        a, b = g.grads.get(k), rg.get(k)
+        if a is None or b is None or b.size == 0:
+            continue
+        if k == "dL_dmeans2D":
+            a, b = a[:, :2], b[:, :2]
+        assert _rel(a, b) <= 1e-4, k
 
 
 @LIVE

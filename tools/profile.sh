@@ -6,7 +6,7 @@ set -u
 tag=$1; variant=$2; shift 2
 root=$(pwd); out=$root/gpurun_out/$tag; mkdir -p "$out"
 export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 5 --warmup 2 --variant $variant --no-cpu-baseline $*"
+cmd="python $root/bench.py --steps 5 --warmup 2 --variant $variant --no-cpu-baseline --no-other-workloads $*"
 cd /tmp
 rm -rf /tmp/prof_$tag; mkdir -p /tmp/prof_$tag
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/trace -- $cmd > "$out/trace_bench.log" 2>&1
