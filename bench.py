@@ -203,6 +203,9 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     stream = torch.cuda.current_stream(dev)
+    for m in marks:   # torch creates the hipEvent at the first record(): do that HERE, not inside the timed region
+        m.record(stream)
+    torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     marks[0].record(stream)
     cum = []

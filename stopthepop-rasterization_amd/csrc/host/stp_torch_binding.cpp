@@ -40,10 +40,12 @@ namespace {
 
 constexpr int64_t BIG_BYTES = 256ll << 20, BIG_STEP = 64ll << 20;
 
-struct Pooled { torch::Tensor t; hipEvent_t ev; };
+struct Pooled { torch::Tensor t; hipEvent_t ev; }; // ev: recorded on the releasing stream (owned by g_events, never destroyed: creating an
+                                                   // event can cost a driver call when the runtime's signal pool grows -- not per step)
 std::mutex g_mutex;
 std::map<int, std::vector<Pooled>> g_free;          // device -> free buffers (oldest first)
 std::unordered_map<uintptr_t, int64_t> g_generation; // data_ptr -> how often the buffer at this address was handed out
+std::unordered_map<uintptr_t, hipEvent_t> g_events;  // data_ptr -> the event that orders reuse of the buffer at this address
 int g_keep = 4;                                       // free buffers kept per device
 int64_t g_max_bytes = -1;                             // optional cap on the pooled bytes per device
 
@@ -92,16 +94,13 @@ void put_back(const torch::Tensor& buf) // caller holds g_mutex
     auto& fl = g_free[buf.get_device()];
     for (auto& p : fl)
         if (p.t.data_ptr() == buf.data_ptr()) return;
-    hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess) {
-        if (hipEventRecord(ev, c10::hip::getCurrentHIPStream(buf.get_device()).stream()) != hipSuccess) { (void)hipEventDestroy(ev); ev = nullptr; }
-    } else ev = nullptr;
-    fl.push_back({buf, ev});
+    hipEvent_t& ev = g_events[(uintptr_t)buf.data_ptr()];
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+    bool recorded = ev && hipEventRecord(ev, c10::hip::getCurrentHIPStream(buf.get_device()).stream()) == hipSuccess;
+    if (!recorded) (void)hipStreamSynchronize(c10::hip::getCurrentHIPStream(buf.get_device()).stream()); // (no event: order reuse the slow way)
+    fl.push_back({buf, recorded ? ev : nullptr});
     auto total = [&]() { int64_t s = 0; for (auto& p : fl) s += p.t.numel(); return s; };
-    while ((int)fl.size() > g_keep || (g_max_bytes >= 0 && fl.size() > 1 && total() > g_max_bytes)) {
-        if (fl.front().ev) (void)hipEventDestroy(fl.front().ev);
-        fl.erase(fl.begin());
-    }
+    while ((int)fl.size() > g_keep || (g_max_bytes >= 0 && fl.size() > 1 && total() > g_max_bytes)) fl.erase(fl.begin());
 }
 
 // The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request.  The library may call the
@@ -129,10 +128,8 @@ struct Resizer {
                 if (hit >= 0) {
                     Pooled p = fl[hit];
                     fl.erase(fl.begin() + hit);
-                    if (p.ev) { // the releasing stream's kernels may still be reading it: order this stream behind them
+                    if (p.ev) // the releasing stream's kernels may still be reading it: order this stream behind them
                         (void)hipStreamWaitEvent(c10::hip::getCurrentHIPStream(p.t.get_device()).stream(), p.ev, 0);
-                        (void)hipEventDestroy(p.ev);
-                    }
                     self->t = p.t;
                 } else self->t = torch::empty({cap}, self->t.options());
                 self->from_pool = true;
@@ -340,7 +337,7 @@ int64_t clear_scratch_pool(int device) // device < 0: all devices; returns the b
     int64_t freed = 0;
     for (auto it = g_free.begin(); it != g_free.end();) {
         if (device >= 0 && it->first != device) { ++it; continue; }
-        for (auto& p : it->second) { freed += p.t.numel(); if (p.ev) (void)hipEventDestroy(p.ev); }
+        for (auto& p : it->second) freed += p.t.numel();
         it = g_free.erase(it);
     }
     return freed;

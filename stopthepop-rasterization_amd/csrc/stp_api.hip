@@ -161,7 +161,8 @@ ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* to
     // instead of reading a log that was never allocated.
     s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
     if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 2 bytes per pixel
-        s.blend_log = c.take<uint32_t>(T * 256 * 256 / 2, &off); note("blend_log", off, T * 256 * 256); // T x 4 waves x 256 records x 64 lanes, 2 B each
+        const size_t recs = T * 4 * (size_t)blend_log_rows() * 64; // T x 4 waves x rows x 64 lanes, 2 B each
+        s.blend_log = c.take<uint32_t>(recs / 2, &off); note("blend_log", off, recs);
     }
     if (total) *total = c.total();
     if (n_names) *n_names = n;
@@ -384,7 +385,11 @@ void stp_timing_enable(int enabled)
 {
     std::lock_guard<std::mutex> l(g_timer_mutex);
     g_timing = enabled != 0;
-    if (g_timing) for (auto& t : g_timers) t.reset();
+    if (g_timing) {
+        for (auto& t : g_timers) t.reset();
+        current_timer().ensure(); // the calling thread's device: its 512 events exist before the first timed call (creating them inside it
+                                  // put 2-3 ms of driver calls into the first step of a timed region)
+    }
 }
 
 int stp_timing_read(float* ms6) // the calling thread's current device

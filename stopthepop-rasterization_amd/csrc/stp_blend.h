@@ -52,6 +52,17 @@ constexpr int LOG_MAX_LIST = 65535;
 #define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured)
 #endif
 constexpr int BLEND_LOG_DEPTH = 256; // records per pixel the log can hold (2 B each: 512 B per pixel)
+#ifndef STP_LOG_UNCOND
+#define STP_LOG_UNCOND 1 // 1: the hierarchical recording forward stores a record in EVERY head step, without a branch -- a step that does
+                         // not blend writes into the slot of the lane's next record, which the next blend overwrites -- and only the
+                         // cursor's advance is conditional.  Needs one spare row per wave for the stores behind the last record.
+#endif
+constexpr int BLEND_LOG_ROWS = BLEND_LOG_DEPTH + (STP_LOG_UNCOND ? 1 : 0); // rows of 64 records in one wave's slice of the log
+constexpr size_t LOG_WAVE_BYTES = (size_t)BLEND_LOG_ROWS * 64 * sizeof(log_t);
+__device__ __forceinline__ char* log_wave_slice(uint32_t* blend_log, int tile, int wave) // [tile][wave][record][lane]
+{
+    return reinterpret_cast<char*>(blend_log) + (size_t)(tile * 4 + wave) * LOG_WAVE_BYTES;
+}
 
 struct FwdPixel {
     float T;

@@ -273,6 +273,41 @@ template <int I, bool FAST = false> __device__ __forceinline__ float depth_along
     return num * rcp;
 }
 
+// ---- the same contraction on the MATRIX pipe -----------------------------------------------------------------------------
+// v_mfma_f32_4x4x1_16b_f32 is sixteen independent 4x4 outer products D[r][j] = A[r] * B[j] + C[r][j], one block per aligned
+// group of four lanes: lane (quad b, j) supplies A = "its" row value and B = its column value and receives, in the four
+// registers of D, row r = 0..3 of ITS column -- i.e. with A = the record word that lane r of the quad fetched and B = my pixel's
+// ray component, D[r] = (entry r's word) * (my ray component) + C[r]: the quad broadcast and the multiply-add of
+// depth_along_ray_quad_ent() for all four candidates of a head group in ONE instruction that issues beside the VALU stream.
+// Every element is an fmaf (one rounding; tools/mfma_probe.hip checks layout and bits on the device), and the three chained
+// instructions of a dot product are exactly fma(c, z, fma(b, y, a * x)) -- the canonical order of depth_along_ray().
+typedef float stp_f4 __attribute__((ext_vector_type(4)));
+struct QuadDepthTerms { stp_f4 a0, a1, a2, num; }; // [r]: candidate r of the quad, at my pixel
+__device__ __forceinline__ QuadDepthTerms depth_terms_quad_mfma(float4 A, float4 B, float4 C, float3 v)
+{
+    const stp_f4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+    QuadDepthTerms t;
+    t.a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A.x, v.x, z, 0, 0, 0);
+    t.a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A.y, v.x, z, 0, 0, 0);
+    t.a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(A.z, v.x, z, 0, 0, 0);
+    t.num = __builtin_amdgcn_mfma_f32_4x4x1f32(B.z, v.x, z, 0, 0, 0);
+    t.a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A.y, v.y, t.a0, 0, 0, 0);
+    t.a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(A.w, v.y, t.a1, 0, 0, 0);
+    t.a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(B.x, v.y, t.a2, 0, 0, 0);
+    t.num = __builtin_amdgcn_mfma_f32_4x4x1f32(B.w, v.y, t.num, 0, 0, 0);
+    t.a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(A.z, v.z, t.a0, 0, 0, 0);
+    t.a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(B.x, v.z, t.a1, 0, 0, 0);
+    t.a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(B.y, v.z, t.a2, 0, 0, 0);
+    t.num = __builtin_amdgcn_mfma_f32_4x4x1f32(C.x, v.z, t.num, 0, 0, 0);
+    return t;
+}
+template <int I, bool FAST = false> __device__ __forceinline__ float depth_from_terms(const QuadDepthTerms& t, float3 v)
+{
+    const float den = fmaf(t.a2[I], v.z, fmaf(t.a1[I], v.y, t.a0[I] * v.x));
+    const float rcp = rcp_ieee<FAST>(fmaxf(0.00001f, den));
+    return t.num[I] * rcp;
+}
+
 // The same for an entry record (BinningState: A = (S00 S01 S02 S11), B = (S12 S22 q.x q.y), C = (q.z . . .)).
 template <int I, bool FAST = false> __device__ __forceinline__ float depth_along_ray_quad_ent(float4 A, float4 B, float4 C, float3 v)
 {
@@ -343,6 +378,33 @@ template <int I> __device__ __forceinline__ float blend_power_quad(float dx, flo
 
 // Smallest "power" (largest contribution) a Gaussian reaches inside an axis-aligned pixel rectangle
 // and where (reference stopthepop_common.cuh:130-174).  patch = rect size - 1.
+// (rcp_x, rcp_y: 1 / (patch_w^2 a) and 1 / (patch_h^2 c) -- they depend on the Gaussian and the patch size only, so a caller that
+// tests one Gaussian against several rectangles of one size computes them once)
+__device__ __forceinline__ float max_contrib_power_rect_r(float4 co, float2 mean, float2 rmin, float2 rmax,
+                                                          float patch_w, float patch_h, float rcp_x, float rcp_y, float2& max_pos)
+{
+#pragma clang fp contract(off)
+    const float x_min_diff = rmin.x - mean.x;
+    const float x_left = x_min_diff > 0.0f ? 1.0f : 0.0f;
+    const float not_in_x = x_left + (mean.x > rmax.x ? 1.0f : 0.0f);
+    const float y_min_diff = rmin.y - mean.y;
+    const float y_above = y_min_diff > 0.0f ? 1.0f : 0.0f;
+    const float not_in_y = y_above + (mean.y > rmax.y ? 1.0f : 0.0f);
+    max_pos = mean;
+    float power = 0.0f;
+    if ((not_in_y + not_in_x) > 0.0f) {
+        const float px = x_left * rmin.x + (1.0f - x_left) * rmax.x;
+        const float py = y_above * rmin.y + (1.0f - y_above) * rmax.y;
+        const float dx = copysignf(patch_w, x_min_diff);
+        const float dy = copysignf(patch_h, y_min_diff);
+        const float diffx = mean.x - px, diffy = mean.y - py;
+        const float tx = not_in_y * saturatef((dx * co.x * diffx + dx * co.y * diffy) * rcp_x);
+        const float ty = not_in_x * saturatef((dy * co.y * diffx + dy * co.z * diffy) * rcp_y);
+        max_pos = make_float2(px + tx * dx, py + ty * dy);
+        power = opacity_factor(mean.x - max_pos.x, mean.y - max_pos.y, co);
+    }
+    return power;
+}
 __device__ __forceinline__ float max_contrib_power_rect(float4 co, float2 mean, float2 rmin, float2 rmax,
                                                         float patch_w, float patch_h, float2& max_pos)
 {

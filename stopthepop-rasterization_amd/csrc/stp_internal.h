@@ -103,6 +103,7 @@ GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total,
 ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
 BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
 
+int blend_log_rows(); // rows of 64 records per wave in the blend log (stp_render_replay.hip: BLEND_LOG_ROWS of stp_blend.h)
 size_t scan_temp_bytes(size_t P);
 size_t sort_temp_bytes(size_t R);
 

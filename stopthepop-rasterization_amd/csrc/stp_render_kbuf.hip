@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     };
 
     // blend log (recording forward): as in stp_render_hier.inc
-    char* const log_wave = RECORD ? reinterpret_cast<char*>(a.blend_log) + ((size_t)(tile * 4 + w) * BLEND_LOG_DEPTH) * 64 * sizeof(log_t) : nullptr;
+    char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w) : nullptr;
     constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
 #if STP_LOG_PACK
     // packed log: a lane holds the first record of a pair and stores both as one dword -- every store of a wave that is in

@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     // Addressing: wave-uniform bases (SGPR pairs) + one 32-bit byte offset per load, so that the loop's loads are
     // `global_load ... v_off, s[base]` without 64-bit address arithmetic (v_lshl_add_u64 issues at half the rate of a
     // 32-bit add on gfx950, tools/valu_rate_bench.hip).
-    const char* const log_wave = reinterpret_cast<const char*>(a.blend_log) + ((size_t)(tile * 4 + __builtin_amdgcn_readfirstlane(w)) * BLEND_LOG_DEPTH) * 64 * sizeof(log_t);
+    const char* const log_wave = log_wave_slice(a.blend_log, tile, __builtin_amdgcn_readfirstlane(w));
     const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
     constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
     auto log_at = [&](uint32_t k) __attribute__((always_inline)) -> int { // record k of this lane
@@ -341,11 +341,22 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     int pos1 = (1 < n) ? log_at(1) : EXHAUSTED;
     Entry en = entry_at(pos);
     const int n_win = (list_len + WINDOW - 1) / WINDOW; // workgroup-uniform
+#ifndef STP_REPLAY_DEPHASE_WIN
+#define STP_REPLAY_DEPHASE_WIN 0
+#endif
+    // De-phasing as in the one-window walk (lane x of every 16-lane row sits out the first x iterations of each window, because
+    // the lanes re-align at every window's end) was built and MEASURED SLOWER in round 3: C2-min replay 1.015 -> 1.06 ms, C3
+    // 1.74 -> 2.08 ms, C5 1.72 -> 1.97 ms (one box, alternating) -- the 15 extra iterations are paid per WINDOW and per wave,
+    // and a window's stragglers already spread the lanes.  Kept as a switch, off.
+    const int dephase = (STP_REPLAY_DEPHASE_WIN && !same_start) ? x : 0;
     for (int win = 0; win < n_win; win++) {
         const int lo = win * WINDOW, hi = lo + WINDOW;
+        int wait = dephase;
         for (;;) {
-            const bool act = pos < hi; // my next record belongs to this window (or to an earlier one: a straggler)
-            if (!__any(act)) break;
+            const bool mine = pos < hi; // my next record belongs to this window (or to an earlier one: a straggler)
+            if (!__any(mine)) break;
+            const bool act = mine && wait <= 0;
+            wait--;
             const Entry cur = en;
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             // issue the next round of loads before touching this step's data
@@ -378,6 +389,8 @@ extern "C" int stp_debug_replay_stats(unsigned long long* out16)
     return (int)e;
 }
 #endif
+
+int blend_log_rows() { return BLEND_LOG_ROWS; }
 
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {

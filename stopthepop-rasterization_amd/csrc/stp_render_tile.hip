@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     else init_fwd_pixel(fp);
     uint32_t contributor = 0;
     float depth_acc = 0.0f;
-    log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(a.blend_log) + ((size_t)(c.tile * 4 + w) * BLEND_LOG_DEPTH) * 64 + lane : nullptr;
+    log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(log_wave_slice(a.blend_log, c.tile, w)) + lane : nullptr;
     int nrec = 0;
     const float4* const eF = a.entF + c.range.x;
     const float4* const eCl = a.entC + c.range.x;
