@@ -455,6 +455,62 @@ __device__ __forceinline__ uint64_t make_sort_key(uint32_t tile, float depth) //
 }
 
 
+// ---- per-(entry, sub-tile) decisions that do not depend on anything a pixel knows, made by the entry gather ---------------
+constexpr int TILE_PX = 16; // (== TILE of stp_internal.h)
+// The hierarchical kernel's 4x4 culling (reference hierarchical_render.cuh:722-743) tests every entry of a tile's list against
+// each of the tile's sixteen 4x4 sub-tiles: opacity * exp(-power at the sub-tile's point of maximum contribution) < 1/255.
+// That is sixteen evaluations per entry whoever makes them -- in the render kernel, which is VALU-bound, they cost 0.034 ms per
+// C2 frame (the four waves of a tile, four sub-tiles each, every batch); the ENTRY GATHER (stp_tilesort.hip, or gather_entries_kernel
+// behind STP_SORT=radix) has the entry's mean and conic in registers anyway and waits for memory three quarters of the time (24 %
+// VALU-busy before this): there the evaluations cost nothing measurable.  Same functions, same
+// operands, same decisions bit for bit: bit 4 w + s of the mask = "the entry is NOT culled for sub-tile column s of
+// sub-tile row w"; the render kernel's batch staging reads the mask instead of the entry's conic.
+__device__ __forceinline__ uint32_t subtile_cull_mask(float4 co, float2 xy, int tile_x, int tile_y)
+{
+    const float rcp_x = rcp_ieee(3.0f * 3.0f * co.x), rcp_y = rcp_ieee(3.0f * 3.0f * co.z);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++)
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const float x0 = (float)(tile_x * TILE_PX + 4 * sx), y0 = (float)(tile_y * TILE_PX + 4 * w);
+            float2 mp;
+            const float p = max_contrib_power_rect_r(co, xy, make_float2(x0, y0), make_float2(x0 + 3.0f, y0 + 3.0f), 3.0f, 3.0f, rcp_x, rcp_y, mp);
+            const bool cull = fminf(0.99f, co.w * exp_blend(-p)) < ALPHA_THRESHOLD;
+            mask |= cull ? 0u : (1u << (4 * w + sx));
+        }
+    return mask;
+}
+
+// The k-buffer kernel's batch staging (stp_render_kbuf.hip) keeps an entry for a 4x4 sub-tile only if its alpha can reach 1/255
+// somewhere in it (the exact minimum of the exponent's form over the rectangle plus a rounding margin: a bound of OURS, the
+// reference has no such test).  Again sixteen evaluations per entry that do not depend on anything a pixel knows: made here.
+__device__ __forceinline__ uint32_t subtile_keep_mask_kbuffer(float4 D, float2 xy, int tile_x, int tile_y)
+{
+    const float T3 = fabsf(D.x) + fabsf(D.y) + fabsf(D.z);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const float y0 = (float)(tile_y * TILE_PX + 4 * w) - xy.y;
+        const float fy = fmaxf(fabsf(y0), fabsf(y0 + 3.0f));
+#pragma unroll
+        for (int sx = 0; sx < 4; sx++) {
+            const float x0 = (float)(tile_x * TILE_PX + 4 * sx) - xy.x;
+            const float p = min_power_rect(D, x0, x0 + 3.0f, y0, y0 + 3.0f);
+            // rounding of the per-pixel exponent against this one: at most a few ulp of the form's terms, all below T3 * far^2
+            const float far = fmaxf(fmaxf(fabsf(x0), fabsf(x0 + 3.0f)), fy);
+            const bool keep = !(D.w * __builtin_amdgcn_exp2f(fmaf(T3 * far * far, 2.0e-6f, -p) * 1.44269502162933349609375f) < ALPHA_THRESHOLD * 0.9999f);
+            mask |= keep ? (1u << (4 * w + sx)) : 0u;
+        }
+    }
+    return mask;
+}
+
+__device__ __forceinline__ uint32_t subtile_mask(int kind, float4 D, float2 xy, int tile_x, int tile_y)
+{
+    return kind == 1 ? subtile_cull_mask(D, xy, tile_x, tile_y) : subtile_keep_mask_kbuffer(D, xy, tile_x, tile_y);
+}
+
 // Workgroup-cooperative staging of BLOCK rows of ROWLEN floats (ROWLEN % 4 == 0) from global memory into LDS rows padded to
 // ROWLEN + 1 words, for a FULL block: all of a thread's 16-byte loads are issued before the first LDS write (the generic
 // loop with a run-time row length computes an integer division per iteration and ends up with ONE load in flight per

@@ -12,6 +12,10 @@
 namespace stp {
 
 constexpr int TILE = 16;
+#ifndef STP_CULL_MASK
+#define STP_CULL_MASK 1 // hierarchical 4x4 culling: the per-(entry, sub-tile) decisions are made by the entry gather (stp_tilesort.hip) and
+                        // travel in the entry records; 0: by the render kernel's batch staging (rounds 1-2)
+#endif
 constexpr size_t ALIGN = 256; // sub-array alignment inside the scratch buffers
 
 enum SortMode { MODE_GLOBAL = 0, MODE_FULL = 1, MODE_KBUFFER = 2, MODE_HIER = 3 };
@@ -20,6 +24,15 @@ enum SortOrder { ORDER_Z = 0, ORDER_DISTANCE = 1, ORDER_PTD_CENTER = 2, ORDER_PT
 inline bool uses_blend_log(const StpSettings& s)
 {
     return s.record_blend_log != 0 && s.debug_visualization == 0 && (s.sort_mode == MODE_HIER || s.sort_mode == MODE_KBUFFER);
+}
+
+// which 16-bit sub-tile mask the entry gather leaves in the spare word of an entry's colour record (stp_device.h: subtile_mask):
+// 1 = the hierarchical mode's 4x4 culling decisions, 2 = the k-buffer kernel's sub-tile pre-test, 0 = none
+inline int subtile_mask_kind(const StpSettings& s)
+{
+    if (!STP_CULL_MASK) return 0;
+    if (s.sort_mode == MODE_HIER && s.hierarchical_4x4_culling) return 1;
+    return s.sort_mode == MODE_KBUFFER ? 2 : 0;
 }
 
 inline bool requires_depth_along_ray(const StpSettings& s) // reference rasterizer.h:66-71

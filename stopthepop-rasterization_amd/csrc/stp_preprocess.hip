@@ -648,28 +648,33 @@ hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const Imag
 // entry gathers its Gaussian's Sigma^-1 pack, conic/opacity, 2D mean and colour ONCE; afterwards every consumer
 // (batch staging, mid and head feeds, blends, the replay backward) reads them with unit stride inside its tile's
 // segment instead of gathering by Gaussian id from four arrays each time.
-__global__ void __launch_bounds__(256) gather_entries_kernel(int R, const uint32_t* __restrict__ point_list, const float4* __restrict__ gpack,
-                                                             const float* __restrict__ features, float4* __restrict__ entA, float4* __restrict__ entB,
-                                                             float4* __restrict__ entC, float4* __restrict__ entD, float4* __restrict__ entF)
+__global__ void __launch_bounds__(256) gather_entries_kernel(int R, const uint32_t* __restrict__ point_list, const uint64_t* __restrict__ keys,
+                                                             const float4* __restrict__ gpack, const float* __restrict__ features,
+                                                             float4* __restrict__ entA, float4* __restrict__ entB, float4* __restrict__ entC,
+                                                             float4* __restrict__ entD, float4* __restrict__ entF, int mask_kind, int gx, uint32_t T)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const int id = (int)point_list[i];
+    if (id < 0) return; // (a padding entry behind the last tile's segment)
     const float4* __restrict__ gp = gpack + 4 * (size_t)id; // one 64-byte line written by preprocess_kernel
     const float4 pa = gp[0], pb = gp[1], pc = gp[2], pd = gp[3];
     entA[i] = pa;
     entB[i] = pb;
     entC[i] = make_float4(pc.x, pc.y, pc.z, __int_as_float(id));
     entD[i] = pd;
-    entF[i] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1], features[3 * (size_t)id + 2], 0.0f);
+    float spare = 0.0f;
+    const uint32_t tile = (uint32_t)(keys[i] >> 32);
+    if (mask_kind && tile < T) spare = __uint_as_float(subtile_mask(mask_kind, pd, make_float2(pc.y, pc.z), (int)(tile % (uint32_t)gx), (int)(tile / (uint32_t)gx)));
+    entF[i] = make_float4(features[3 * (size_t)id], features[3 * (size_t)id + 1], features[3 * (size_t)id + 2], spare);
 }
 
 hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st)
 {
     if (R <= 0 || (f.s.sort_mode != MODE_HIER && f.s.sort_mode != MODE_KBUFFER)) return hipSuccess;
     const float* features = f.colors_precomp ? f.colors_precomp : g.rgb;
-    hipLaunchKernelGGL(gather_entries_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, b.point_list, g.gpack, features, b.entA, b.entB, b.entC,
-                       b.entD, b.entF);
+    hipLaunchKernelGGL(gather_entries_kernel, dim3((R + 255) / 256), dim3(256), 0, st, R, b.point_list, b.keys, g.gpack, features, b.entA, b.entB, b.entC,
+                       b.entD, b.entF, subtile_mask_kind(f.s), f.gx, (uint32_t)(f.gx * f.gy));
     return hipGetLastError();
 }
 

@@ -220,6 +220,13 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
         const int ep = base + e;
         bool keepA = false, keepB = false;
         if (ep < total) {
+#if STP_CULL_MASK
+            // (the sixteen sub-tile verdicts of this entry were computed by the entry gather, stp_tilesort.hip: subtile_keep_mask_kbuffer)
+            const uint32_t mask = __float_as_uint(*reinterpret_cast<const float*>(reinterpret_cast<const char*>(eF) + ((uint32_t)ep << 4) + 12));
+            const uint32_t mine = mask >> (4 * w + 2 * half);
+            keepA = (mine & 1u) != 0u;
+            keepB = (mine & 2u) != 0u;
+#else
             const float4 C = ent_row(eC, ep), D = ent_row(eD, ep);
             const float x0A = sxA - C.y, x0B = sxB - C.y, y0 = syf - C.z;
             const float pA = min_power_rect(D, x0A, x0A + 3.0f, y0, y0 + 3.0f);
@@ -230,6 +237,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
             const float fA = fmaxf(fmaxf(fabsf(x0A), fabsf(x0A + 3.0f)), fy), fB = fmaxf(fmaxf(fabsf(x0B), fabsf(x0B + 3.0f)), fy);
             keepA = !(D.w * __builtin_amdgcn_exp2f(fmaf(T3 * fA * fA, 2.0e-6f, -pA) * 1.44269502162933349609375f) < ALPHA_THRESHOLD * 0.9999f);
             keepB = !(D.w * __builtin_amdgcn_exp2f(fmaf(T3 * fB * fB, 2.0e-6f, -pB) * 1.44269502162933349609375f) < ALPHA_THRESHOLD * 0.9999f);
+#endif
         }
         const unsigned long long balA = __ballot(keepA), balB = __ballot(keepB);
         const unsigned int mA = (unsigned int)(balA >> (32 * half)), mB = (unsigned int)(balB >> (32 * half));

@@ -12,6 +12,7 @@
 // 8-bit counting passes (id bytes first when the segment is not in id order yet, then the four depth bytes) through the
 // otherwise unused unsorted arrays.  Same sorted list, bit for bit.
 #include "stp_internal.h"
+#include "stp_device.h"
 #include <rocprim/block/block_radix_sort.hpp>
 
 namespace stp {
@@ -32,18 +33,23 @@ struct TileSortArgs {
     const float4* gpack;      // nullptr: no entry records (GLOBAL mode)
     const float* features;
     int id_passes;            // long segments: counting passes on the id bytes before the depth passes (0: already in id order)
+    int gx;                   // tiles per row
+    int cull_mask;            // leave every entry's 16-bit sub-tile mask in entF.w (see write_entry): 1 = hierarchical mode's 4x4 culling, 2 = the k-buffer kernel's sub-tile pre-test
     float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
 };
 
-__device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int id)
+__device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int id, int tile)
 {
     const float4* __restrict__ gp = a.gpack + 4 * (size_t)id; // one 64-byte line written by preprocess_kernel
     const float4 pa = gp[0], pb = gp[1], pc = gp[2], pd = gp[3];
+    const float3 col = make_float3(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2]);
     a.entA[i] = pa;
     a.entB[i] = pb;
     a.entC[i] = make_float4(pc.x, pc.y, pc.z, __int_as_float(id));
     a.entD[i] = pd;
-    a.entF[i] = make_float4(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2], 0.0f);
+    float spare = 0.0f;
+    if (a.cull_mask) spare = __uint_as_float(subtile_mask(a.cull_mask, pd, make_float2(pc.y, pc.z), tile % a.gx, tile / a.gx)); // (stp_device.h)
+    a.entF[i] = make_float4(col.x, col.y, col.z, spare);
 }
 
 // Segments of 1025 .. 4096 entries that arrive in Gaussian-id order (the tile-bit radix sort is stable): a stable sort on the
@@ -102,7 +108,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
 
     if constexpr (CAP == TS_CAP) {
         if (n <= CAP && a.id_passes == 0) { // (segments in id order: always, unless the list was binned through atomic cursors)
-            auto we = [&](int i, int id) __attribute__((always_inline)) { if (a.gpack) write_entry(a, (size_t)range.x + i, id); };
+            auto we = [&](int i, int id) __attribute__((always_inline)) { if (a.gpack) write_entry(a, (size_t)range.x + i, id, tile); };
             if (n <= 2048) Radix8::run(*reinterpret_cast<typename Radix8::Sort::storage_type*>(s_raw), keys, list, n, tid, we);
             else Radix16::run(*reinterpret_cast<typename Radix16::Sort::storage_type*>(s_raw), keys, list, n, tid, we);
             return;
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
             const int id = (int)(uint32_t)k;
             keys[i] = tile_bits | (k >> 32);
             list[i] = (uint32_t)id;
-            if (a.gpack) write_entry(a, (size_t)range.x + i, id);
+            if (a.gpack) write_entry(a, (size_t)range.x + i, id, tile);
         }
         return;
     }
@@ -188,7 +194,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
         __syncthreads();
     }
     if (a.gpack)
-        for (int i = tid; i < n; i += 256) write_entry(a, (size_t)range.x + i, (int)list[i]);
+        for (int i = tid; i < n; i += 256) write_entry(a, (size_t)range.x + i, (int)list[i], tile);
 }
 
 } // namespace
@@ -204,6 +210,8 @@ hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g,
     const bool entries = f.s.sort_mode == MODE_HIER || f.s.sort_mode == MODE_KBUFFER;
     a.gpack = entries ? g.gpack : nullptr;
     a.features = f.colors_precomp ? f.colors_precomp : g.rgb;
+    a.gx = f.gx;
+    a.cull_mask = subtile_mask_kind(f.s);
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     hipLaunchKernelGGL((tile_sort_gather_kernel<TS_SMALL, 0>), dim3(f.gx * f.gy), dim3(256), 0, st, a);
     hipLaunchKernelGGL((tile_sort_gather_kernel<TS_CAP, TS_SMALL>), dim3(f.gx * f.gy), dim3(256), 0, st, a);
