@@ -485,9 +485,25 @@ __device__ __forceinline__ uint32_t subtile_cull_mask(float4 co, float2 xy, int 
 // The k-buffer kernel's batch staging (stp_render_kbuf.hip) keeps an entry for a 4x4 sub-tile only if its alpha can reach 1/255
 // somewhere in it (the exact minimum of the exponent's form over the rectangle plus a rounding margin: a bound of OURS, the
 // reference has no such test).  Again sixteen evaluations per entry that do not depend on anything a pixel knows: made here.
+// min_power_rect() for a caller that tests one conic against many rectangles: the two quotients -B X / C and -B Y / A become products
+// with reciprocals taken once (v_rcp_f32, 1 ulp: the parabola's vertex moves by 1e-7 of itself, where the form is stationary, and the
+// callers' margin covers far more).  A bound of OURS, not a reference decision.
+__device__ __forceinline__ float min_power_rect_r(float4 co, float nb_over_c, float nb_over_a, float x0, float x1, float y0, float y1)
+{
+    const float A = co.x, B = co.y, C = co.z;
+    if (!(A > 0.0f && C > 0.0f)) return 0.0f;
+    if (x0 <= 0.0f && x1 >= 0.0f && y0 <= 0.0f && y1 >= 0.0f) return 0.0f;
+    auto q = [&](float dx, float dy) { return 0.5f * (A * dx * dx + C * dy * dy) + B * dx * dy; };
+    auto on_x_edge = [&](float X) { return q(X, fminf(fmaxf(nb_over_c * X, y0), y1)); }; // dx = X fixed, dy free in [y0, y1]
+    auto on_y_edge = [&](float Y) { return q(fminf(fmaxf(nb_over_a * Y, x0), x1), Y); };
+    const float m = fminf(fminf(on_x_edge(x0), on_x_edge(x1)), fminf(on_y_edge(y0), on_y_edge(y1)));
+    return m == m ? fmaxf(m, 0.0f) : 0.0f;
+}
+
 __device__ __forceinline__ uint32_t subtile_keep_mask_kbuffer(float4 D, float2 xy, int tile_x, int tile_y)
 {
     const float T3 = fabsf(D.x) + fabsf(D.y) + fabsf(D.z);
+    const float nb_over_c = -D.y * __builtin_amdgcn_rcpf(D.z), nb_over_a = -D.y * __builtin_amdgcn_rcpf(D.x);
     uint32_t mask = 0;
 #pragma unroll
     for (int w = 0; w < 4; w++) {
@@ -496,7 +512,7 @@ __device__ __forceinline__ uint32_t subtile_keep_mask_kbuffer(float4 D, float2 x
 #pragma unroll
         for (int sx = 0; sx < 4; sx++) {
             const float x0 = (float)(tile_x * TILE_PX + 4 * sx) - xy.x;
-            const float p = min_power_rect(D, x0, x0 + 3.0f, y0, y0 + 3.0f);
+            const float p = min_power_rect_r(D, nb_over_c, nb_over_a, x0, x0 + 3.0f, y0, y0 + 3.0f);
             // rounding of the per-pixel exponent against this one: at most a few ulp of the form's terms, all below T3 * far^2
             const float far = fmaxf(fmaxf(fabsf(x0), fabsf(x0 + 3.0f)), fy);
             const bool keep = !(D.w * __builtin_amdgcn_exp2f(fmaf(T3 * far * far, 2.0e-6f, -p) * 1.44269502162933349609375f) < ALPHA_THRESHOLD * 0.9999f);
