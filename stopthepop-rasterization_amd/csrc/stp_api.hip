@@ -351,6 +351,15 @@ size_t stp_image_buffer_size(int width, int height)
     return total;
 }
 
+size_t stp_blend_log_bytes(int width, int height)
+{
+    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    size_t plain = 0, with_log = 0;
+    carve_image(nullptr, (size_t)width * height, T, false, &plain);
+    carve_image(nullptr, (size_t)width * height, T, true, &with_log);
+    return with_log - plain;
+}
+
 static int find_name(const NamedOffset* names, int n, const char* name, size_t* offset, size_t* count)
 {
     for (int i = 0; i < n; i++)

@@ -46,6 +46,12 @@ namespace {
 #ifndef STP_REPLAY_OCC
 #define STP_REPLAY_OCC 4
 #endif
+#ifndef STP_REPLAY_COPIES
+#define STP_REPLAY_COPIES 1 // 2: two sets of sums per workgroup, one for sub-tile rows 0-1 and one for rows 2-3 of every wave -- the round-2 verdict's
+                            // experiment against same-address serialisation of the LDS adds.  MEASURED (round 3, C2-full, one box): 72 KB of LDS
+                            // = two workgroups per CU 1.374 ms, windows of 256 positions at four workgroups per CU 1.155 ms, against 0.946 ms:
+                            // the kernel lives on its four waves per SIMD (latency), and an average C2 list (321 entries) needs the 512 window.
+#endif
 #ifndef STP_REPLAY_COLOR32
 #define STP_REPLAY_COLOR32 0 // 1: the three colour sums as 32-bit fixed point (ds_add_u32 costs half of ds_add_u64, also on shared addresses), the
                              // six geometric ones stay 64-bit.  MEASURED (round 3, one box, alternating): C2-full 0.947 against 0.928 ms,
@@ -76,7 +82,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     __shared__ unsigned int s_acc32[3 * WINDOW];     // [term 0..2][position - window start]: the three colour sums, 32-bit fixed point
     constexpr int ACC64_FIRST = 3;
 #else
-    __shared__ unsigned long long s_acc[9 * WINDOW]; // [term][position - window start]
+    __shared__ unsigned long long s_acc[STP_REPLAY_COPIES * 9 * WINDOW]; // [copy][term][position - window start]
     constexpr int ACC64_FIRST = 0;
 #endif
     double* const s_accd = reinterpret_cast<double*>(s_acc); // STP_REPLAY_F64: the same sums as doubles (ds_add_f64)
@@ -94,7 +100,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     const int list_len = (int)(range.y - range.x);
     if (list_len <= 0) return;
 
-    for (int i = (int)threadIdx.x; i < (9 - ACC64_FIRST) * WINDOW; i += 256) s_acc[i] = 0ull;
+    for (int i = (int)threadIdx.x; i < STP_REPLAY_COPIES * (9 - ACC64_FIRST) * WINDOW; i += 256) s_acc[i] = 0ull;
+    const int acc_copy = (STP_REPLAY_COPIES == 2 ? (lane >> 5) : 0) * 9 * WINDOW; // (two copies: sub-tile rows 0-1 / 2-3 of the wave add to their own)
 #if STP_REPLAY_COLOR32
     for (int i = (int)threadIdx.x; i < 3 * WINDOW; i += 256) s_acc32[i] = 0u;
 #endif
@@ -225,7 +232,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                     // round-to-nearest integer of g*scale through the 1.5*2^52 trick (|g*scale| < 2^51 + margin)
                     const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
                     const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
-                    atomicAdd(&s_acc[(kk - ACC64_FIRST) * WINDOW + (cur_pos - lo)], (unsigned long long)qv);
+                    atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + (cur_pos - lo)], (unsigned long long)qv);
                 }
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
 #endif
@@ -258,7 +265,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                     continue;
                 }
 #endif
-                const long long v = (long long)s_acc[(term - ACC64_FIRST) * WINDOW + p];
+                long long v = (long long)s_acc[(term - ACC64_FIRST) * WINDOW + p];
+                if (STP_REPLAY_COPIES == 2) { v += (long long)s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p]; s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p] = 0ull; }
                 if (v != 0) {
                     s_acc[(term - ACC64_FIRST) * WINDOW + p] = 0ull;
                     atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)((double)v * fx_inv));

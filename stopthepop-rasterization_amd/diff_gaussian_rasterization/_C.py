@@ -70,6 +70,8 @@ def _load():
     L.stp_geometry_buffer_size.argtypes = [ci, ctypes.POINTER(StpSettings)]
     L.stp_binning_buffer_size.argtypes = [ci]
     L.stp_image_buffer_size.argtypes = [ci, ci]
+    L.stp_blend_log_bytes.argtypes = [ci, ci]
+    L.stp_blend_log_bytes.restype = ctypes.c_size_t
     szp = ctypes.POINTER(ctypes.c_size_t)
     L.stp_geometry_layout.argtypes = [ci, ctypes.POINTER(StpSettings), ctypes.c_char_p, szp, szp]
     L.stp_binning_layout.argtypes = [ci, ctypes.c_char_p, szp, szp]
@@ -167,8 +169,8 @@ def backward_mode() -> str:
 
 
 def blend_log_bytes(width: int, height: int) -> int:
-    """Bytes of the blend log of one forward at this resolution (512 B per pixel of the 16x16 tile grid)."""
-    return ((int(width) + 15) // 16) * ((int(height) + 15) // 16) * 256 * 256 * 2
+    """Bytes of the blend log of one forward at this resolution (514 B per pixel of the 16x16 tile grid; the library's own figure)."""
+    return int(_load().stp_blend_log_bytes(int(width), int(height)))
 
 
 class LogLease:

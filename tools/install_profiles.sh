@@ -1,9 +1,9 @@
 #!/bin/bash
-# Copy what tools/round_profiles.sh <tag> left under gpurun_out/ into profiles/r02_* (the committed evidence), with traffic.json
+# Copy what tools/round_profiles.sh <tag> left under gpurun_out/ into profiles/<dst>_* (the committed evidence), with traffic.json
 # pointing at the committed directories.   usage: tools/install_profiles.sh r02f [r02]
-tag=$1; dst=${2:-r02}
+tag=$1; dst=${2:-$1}
 for w in full min full_fwd c1 c3 c4_fwd c5 l1 c2l; do [ -f gpurun_out/$tag/bench_$w.json ] && cp gpurun_out/$tag/bench_$w.json profiles/${dst}_bench_$w.json; done
-for v in full min; do for f in kernel_stats.csv pmc1.txt pmc2.txt pmc3.txt pmc4.txt pmc5.txt pmc6.txt; do cp gpurun_out/${tag}_$v/$f profiles/${dst}_$v/$f; done; done
+for v in full min; do mkdir -p profiles/${dst}_$v; for f in kernel_stats.csv pmc1.txt pmc2.txt pmc3.txt pmc4.txt pmc5.txt pmc6.txt; do cp gpurun_out/${tag}_$v/$f profiles/${dst}_$v/$f; done; done
 python - "$tag" "$dst" <<'PY'
 import json, sys
 tag, dst = sys.argv[1], sys.argv[2]

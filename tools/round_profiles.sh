@@ -1,19 +1,19 @@
 #!/bin/bash
 # One GPU-box call that refreshes everything under profiles/ for a round: bench lines of every workload (no profiler
 # attached, taken FIRST), then kernel trace + the six PMC passes of C2-full and C2-min, then profiles/traffic.json.
-#   usage (on the GPU box, from the repo root): tools/round_profiles.sh r02
+#   usage (on the GPU box, from the repo root): tools/round_profiles.sh r03
 set -u
 tag=${1:-rXX}
 out=gpurun_out/${tag}
 mkdir -p $out
-python bench.py > $out/bench_full.json 2> $out/bench_full.err
-python bench.py --variant min --no-cpu-baseline > $out/bench_min.json 2>/dev/null
-python bench.py --fwd-only --no-cpu-baseline > $out/bench_full_fwd.json 2>/dev/null
-python bench.py --workload C1 --steps 500 --warmup 50 --no-cpu-baseline > $out/bench_c1.json 2>/dev/null
-python bench.py --workload C3 --no-cpu-baseline > $out/bench_c3.json 2>/dev/null
-python bench.py --workload C4 --no-cpu-baseline > $out/bench_c4_fwd.json 2>/dev/null
-python bench.py --workload C5 --no-cpu-baseline > $out/bench_c5.json 2>/dev/null
-python bench.py --workload L1 --steps 10 --no-cpu-baseline > $out/bench_l1.json 2>/dev/null
+python bench.py > $out/bench_full.json 2> $out/bench_full.err   # (the driver's line: headline + checker legs + other_workloads)
+python bench.py --variant min --no-cpu-baseline --no-other-workloads > $out/bench_min.json 2>/dev/null
+python bench.py --fwd-only --no-cpu-baseline --no-other-workloads > $out/bench_full_fwd.json 2>/dev/null
+python bench.py --workload C1 --steps 500 --warmup 50 --no-cpu-baseline --no-other-workloads > $out/bench_c1.json 2>/dev/null
+python bench.py --workload C3 --no-cpu-baseline --no-other-workloads > $out/bench_c3.json 2>/dev/null
+python bench.py --workload C4 --no-cpu-baseline --no-other-workloads > $out/bench_c4_fwd.json 2>/dev/null
+python bench.py --workload C5 --no-cpu-baseline --no-other-workloads > $out/bench_c5.json 2>/dev/null
+python bench.py --workload L1 --steps 10 --no-cpu-baseline --no-other-workloads > $out/bench_l1.json 2>/dev/null
 tools/profile.sh ${tag}_full full > /dev/null 2>&1
 tools/profile.sh ${tag}_min min > /dev/null 2>&1
 python tools/traffic_json.py C2-full gpurun_out/${tag}_full gpurun_out/${tag}/traffic.json
