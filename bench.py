@@ -325,7 +325,7 @@ def hbm_ceilings(dev):
 OTHER_WORKLOADS = (("C2-min", "C2", "min", False), ("C3", "C3", "full", False), ("C4-1gpu-fwd", "C4", "full", True), ("C5", "C5", "full", False))
 
 
-def other_workloads(dev, steps=5, warmup=2):
+def other_workloads(dev, steps=10, warmup=3):
     """The BASELINE configurations that are not the headline, `steps` timed steps each on the same code in the same process
     (same harness as the headline: wall clock between two synchronisations, stage hipEvents, SURVEY 8(d) bytes)."""
     out = {}
@@ -373,7 +373,7 @@ def main():
     ap.add_argument("--fwd-only", action="store_true")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps (device clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-other-workloads", action="store_true", help="N == 1: leave out the other_workloads object (C2-min, C3, C4 on one GPU, C5; 5 steps each)")
+    ap.add_argument("--no-other-workloads", action="store_true", help="N == 1: leave out the other_workloads object (C2-min, C3, C4 on one GPU, C5; 10 steps each)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--train-forward-only", action="store_true",
                     help="debug: forward passes that expect a backward (recording forward) without running it; read stage_ms only")

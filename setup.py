@@ -2,11 +2,13 @@
 
     pip install --no-build-isolation -e .        # or: pip install --no-build-isolation .
 
-builds libstp_raster.so with hipcc for gfx950 (make -C stopthepop-rasterization_amd/csrc; no torch C++ extension,
-no hipify pass) and installs the package `diff_gaussian_rasterization` with the library as package data.
+builds libstp_raster.so with hipcc for gfx950 (make -C stopthepop-rasterization_amd/csrc) and the native torch binding
+_stp_host with g++ (csrc/host/build_host.py: host code only -- no kernel goes through a torch extension, hence no hipify
+pass) and installs the package `diff_gaussian_rasterization` with both as package data.
 The repository's test-side directories (oracle/, tests/, tools/) are not installed."""
 import os
 import subprocess
+import sys
 
 from setuptools import setup
 from setuptools.command.build_py import build_py
@@ -19,16 +21,17 @@ class BuildWithLibrary(build_py):
     def run(self):
         jobs = str(min(8, os.cpu_count() or 1))
         subprocess.check_call(["make", "-C", os.path.join(ROOT, PKG_PARENT, "csrc"), "-j", jobs, "ARCH=gfx950"])
+        subprocess.check_call([sys.executable, os.path.join(ROOT, PKG_PARENT, "csrc", "host", "build_host.py")])
         super().run()
 
 
 setup(
     name="diff_gaussian_rasterization",
-    version="0.2.0",
+    version="0.3.0",
     description="MI355X-native sorted Gaussian-splat rasterizer behind the StopThePop diff_gaussian_rasterization API",
     packages=["diff_gaussian_rasterization"],
     package_dir={"": PKG_PARENT},
-    package_data={"diff_gaussian_rasterization": ["libstp_raster.so"]},
+    package_data={"diff_gaussian_rasterization": ["libstp_raster.so", "_stp_host*.so"]},
     cmdclass={"build_py": BuildWithLibrary},
     python_requires=">=3.9",
     install_requires=[],   # torch (ROCm build) is expected in the environment, as with the reference
