@@ -290,7 +290,10 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #ifndef STP_REPLAY_HOIST
 #define STP_REPLAY_HOIST 0 // 1: do not re-zero the terms of a lane that does not blend in a step (round 2).  Its partner in the DPP merge
                            // multiplies them by zero -- and 0 x Inf is NaN: a lane whose last blend overflowed would poison the sums of
-                           // OTHER Gaussians.  Re-zeroing is nine full-rate v_mov; measured no slower (0.920-0.929 against 0.947 ms).
+                           // OTHER Gaussians.  Re-zeroing is nine full-rate v_mov per step: 0.951 against 0.929 ms on the final code of round 3
+                           // (three alternating runs; the first measurement, beside another change, had shown no difference).  Zeroing only
+                           // in the step in which a lane stops blending (ballot difference + branch) was built too: 1.046 ms -- de-phased
+                           // lanes stop in different steps, the branch is taken most of the time and splits the loop body.  Safety wins.
 #endif
     // (STP_REPLAY_HOIST: the terms of a lane that does not blend in a step are not zeroed -- they keep the lane's last,
     // finite, values; the merge multiplies such a partner by zero and the lane itself adds nothing)
