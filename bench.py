@@ -190,10 +190,17 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     _C, dev = wl._C, wl.dev
     # bring the device out of its idle power state before the contract's W warm-up steps: the first process on a fresh box
     # otherwise measures the clock ramp (seen: 299 instead of 337 frames/s); untimed, like the warm-up itself
-    t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < prewarm_seconds:
-        wl.step()
+    if wl.sharded:
+        # (a tile-row step contains collectives: every rank must run the SAME number of steps -- a time-based loop would let the
+        # ranks disagree and deadlock in the exchange; found by the one-GPU self-test of round 3, `--test-one-gpu`)
+        for _ in range(10 if prewarm_seconds > 0 else 0):
+            wl.step()
         torch.cuda.synchronize(dev)
+    else:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < prewarm_seconds:
+            wl.step()
+            torch.cuda.synchronize(dev)
     for _ in range(warmup):
         wl.step()
     barrier()
@@ -379,6 +386,9 @@ def main():
                     help="debug: forward passes that expect a backward (recording forward) without running it; read stage_ms only")
     ap.add_argument("--per-step", action="store_true", help="debug: print cumulative wall time after each timed step")
     ap.add_argument("--force-shard", action="store_true", help="use the tile-row sharded path even with one rank (self-test of the exchange code)")
+    ap.add_argument("--test-one-gpu", action="store_true",
+                    help="self-test of the N > 1 code path on a box with ONE GPU: every rank uses cuda:0 and the process group is gloo (host-staged "
+                         "exchange); the numbers mean nothing")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the result of rank 0.  Libraries write there too (RCCL prints a five-line version
@@ -395,7 +405,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs WORLD_SIZE={args.gpus} (launch with torch.distributed.run)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.test_one_gpu else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     rccl_ranks = None
@@ -403,10 +413,14 @@ def main():
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.test_one_gpu:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         dist = dist_mod
+        coll_dev = torch.device("cpu") if args.test_one_gpu else dev   # (gloo: small control tensors live on the host)
         # the first collective: every rank contributes 1, so the sum IS the number of ranks RCCL connected
-        ones = torch.ones(1, device=dev, dtype=torch.int32)
+        ones = torch.ones(1, device=coll_dev, dtype=torch.int32)
         dist.all_reduce(ones)
         rccl_ranks = {"world_size": int(dist.get_world_size()), "all_reduce_of_ones": int(ones.item()), "backend": dist.get_backend()}
 
@@ -416,45 +430,46 @@ def main():
     if args.shard is None:
         args.shard = "tilerows"
     sharded = (world > 1 or args.force_shard) and args.shard == "tilerows"
-    wl = Workload(args.workload, args.variant, dev, fwd_only=fwd_only, scale=args.scale, dist=dist, rank=rank, world=world,
-                  sharded=sharded, train_forward_only=args.train_forward_only)
-    scene, sdict, es, gy = wl.scene, wl.sdict, wl.es, wl.gy
-    fwd_only = wl.fwd_only
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    dt, stage_ms, step_stats, cum = timed_region(wl, args.steps, args.warmup, args.prewarm_seconds, barrier, per_step=args.per_step)
-    if args.per_step and rank == 0:
-        print("cumulative ms after each step:", cum, "reserved GB:", round(torch.cuda.memory_reserved(dev) / 2**30, 2),
-              "num_alloc_retries:", torch.cuda.memory_stats(dev).get("num_alloc_retries"), "segments:",
-              torch.cuda.memory_stats(dev).get("segment.all.allocated"), file=sys.stderr, flush=True)
+    def measure(shard_rows, steps, warmup, prewarm):
+        """One Workload + one timed region (contract: W warm-up steps, EXACTLY K steps between barrier + synchronise, MAX over ranks)."""
+        w = Workload(args.workload, args.variant, dev, fwd_only=fwd_only, scale=args.scale, dist=dist, rank=rank, world=world,
+                     sharded=shard_rows, train_forward_only=args.train_forward_only)
+        dt_, stage_, stats_, cum_ = timed_region(w, steps, warmup, prewarm, barrier, per_step=args.per_step)
+        if args.per_step and rank == 0:
+            print("cumulative ms after each step:", cum_, "reserved GB:", round(torch.cuda.memory_reserved(dev) / 2**30, 2),
+                  "num_alloc_retries:", torch.cuda.memory_stats(dev).get("num_alloc_retries"), "segments:",
+                  torch.cuda.memory_stats(dev).get("segment.all.allocated"), file=sys.stderr, flush=True)
+        if dist is not None:
+            tt = torch.tensor([dt_], device=coll_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_ = float(tt.item())
+        return w, dt_, stage_, stats_
 
-    if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    frames_per_step = world if (world > 1 and not sharded) else 1
-    value = frames_per_step * args.steps / dt
-    ms_per_step = 1000.0 * dt / args.steps
-
-    def build_out():
-        roofline, info = describe(wl, stage_ms, ms_per_step)
+    def line(w, dt_, stage_ms, step_stats, shard_rows, steps):
+        """The JSON line of one measurement (rank 0)."""
+        scene, sdict = w.scene, w.sdict
+        frames_per_step = world if (world > 1 and not shard_rows) else 1
+        value = frames_per_step * steps / dt_
+        ms_per_step = 1000.0 * dt_ / steps
+        roofline, info = describe(w, stage_ms, ms_per_step)
         P, P_v, R, T, B, mode, order = info["P"], info["P_visible"], info["num_rendered"], info["tiles"], info["blended_pairs"], info["mode"], info["order"]
         des, prof, prof_note, kname, dom_ms = info["des"], info["prof"], info["prof_note"], info["kname"], info["dom_ms"]
         out = {
             "metric": "fwd+bwd frames/sec at 1920×1080, 1M Gaussians; PSNR vs reference",
-            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if shard_rows else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}-{args.variant}: {P} Gaussians, {scene.W}x{scene.H}, SH degree 3, "
                                    f"sort_mode={mode} sort_order={order} culling={sdict['culling_settings']} "
-                                   f"{'fwd' if fwd_only else 'fwd+bwd'}",
+                                   f"{'fwd' if w.fwd_only else 'fwd+bwd'}",
                        "P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B,
-                       "parallelism": (f"tilerows{world}" if sharded else f"frames{world}") if world > 1 else "single",
+                       "parallelism": (f"tilerows{world}" if shard_rows else f"frames{world}") if world > 1 else "single",
                        "scale": args.scale},
             "step_ms": step_stats,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
@@ -477,23 +492,27 @@ def main():
                            "source": prof_note}
         return out
 
-    out = None
-    if rank == 0:
-        out = build_out()
+    def summary(o):
+        return {k: o[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling", "stage_ms") if k in o} | {"parallelism": o["config"]["parallelism"]}
 
-    # side measurement (N > 1): the OTHER way of sharing the N GPUs -- every rank its own frame, no data-path collective
-    # (weak scaling) when the headline is the tile-row mode, one frame by tile rows when the headline is frames.  The
-    # headline `out` is complete before it starts, and a watchdog prints it with an error field should the side run hang.
-    side, side_key = None, None
-    want_side = world > 1 and ((sharded and not args.no_frame_shard_probe) or (not sharded and not args.no_tile_shard_probe))
-    if want_side:
+    # N == 1 (or one explicitly chosen mode): one measurement.  N > 1 with the tile-row headline: the mode WITHOUT a data-path
+    # collective -- every rank its own frame -- is measured FIRST and kept as the fallback line; the tile-row exchange (never run by us
+    # on more than one RCCL rank) then runs under a watchdog: should it hang or fail, the fallback line is printed with an error field
+    # instead of nothing.
+    out, wl = None, None
+    side_first = world > 1 and ((sharded and not args.no_frame_shard_probe) or (not sharded and not args.no_tile_shard_probe))
+    fallback = None
+    if side_first and sharded:
+        wl_f, dt_f, stage_f, stats_f = measure(False, args.steps, args.warmup, args.prewarm_seconds)
+        if rank == 0:
+            fallback = line(wl_f, dt_f, stage_f, stats_f, False, args.steps)
+        wl_f.free()
         import threading
-        side_key = "frame_shard" if sharded else "tile_shard"
 
         def bail():
             if rank == 0:
-                o = dict(out)
-                o[side_key] = {"error": f"timed out after {args.probe_timeout:.0f} s; the headline is unaffected"}
+                o = dict(fallback)
+                o["tile_shard"] = {"error": f"the tile-row exchange did not complete within {args.probe_timeout:.0f} s: this line is the frame-sharded measurement"}
                 os.write(result_fd, (json.dumps(o) + "\n").encode())
             os._exit(0)
 
@@ -501,30 +520,50 @@ def main():
         watchdog.daemon = True
         watchdog.start()
         try:
-            wl2 = Workload(args.workload, args.variant, dev, fwd_only=fwd_only, scale=args.scale, dist=dist, rank=rank, world=world,
-                           sharded=not sharded)
-            k2 = max(1, min(args.steps, 10))
-            dt2, stage2, _, _ = timed_region(wl2, k2, 2, 0.0, barrier)
-            tt2 = torch.tensor([dt2], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt2, op=dist.ReduceOp.MAX)
-            dt2 = float(tt2.item())
-            if sharded:
-                side = {"value": round(world * k2 / dt2, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * dt2 / k2, 4), "steps": k2,
-                        "scaling": "weak", "parallelism": f"frames{world}",
-                        "what": "every rank renders its own frame (the metric's unit is a frame and frames are independent): no data-path collective"}
-            else:
-                side = {"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_frame": round(1000.0 * dt2 / k2, 4), "steps": k2,
-                        "scaling": "strong", "parallelism": f"tilerows{world}",
-                        "exchange": "three channel segments per peer sent straight into rank 0's frame (grouped RCCL send/recv) + all-reduce of 36 B per Gaussian"}
-            wl2.free()
-        except Exception as ex:  # the headline above stands on its own
-            side = {"error": repr(ex)[:300]}
+            wl, dt, stage_ms, step_stats = measure(True, args.steps, args.warmup, 0.2)
+            if rank == 0:
+                out = line(wl, dt, stage_ms, step_stats, True, args.steps)
+                out["frame_shard"] = summary(fallback) | {"what": "every rank renders its own frame (the metric's unit is a frame and frames are independent): no data-path collective"}
+        except Exception as ex:
+            if rank == 0:
+                out = dict(fallback)
+                out["tile_shard"] = {"error": repr(ex)[:300]}
+            wl = None
         watchdog.cancel()
+    else:
+        wl, dt, stage_ms, step_stats = measure(sharded, args.steps, args.warmup, args.prewarm_seconds)
+        if rank == 0:
+            out = line(wl, dt, stage_ms, step_stats, sharded, args.steps)
+        if side_first:   # (--shard frames: the tile-row mode as the side measurement, under the watchdog)
+            import threading
+
+            def bail2():
+                if rank == 0:
+                    o = dict(out)
+                    o["tile_shard"] = {"error": f"timed out after {args.probe_timeout:.0f} s; the headline is unaffected"}
+                    os.write(result_fd, (json.dumps(o) + "\n").encode())
+                os._exit(0)
+
+            watchdog = threading.Timer(args.probe_timeout, bail2)
+            watchdog.daemon = True
+            watchdog.start()
+            try:
+                k2 = max(1, min(args.steps, 10))
+                wl2, dt2, stage2, stats2 = measure(True, k2, 2, 0.0)
+                if rank == 0:
+                    out["tile_shard"] = summary(line(wl2, dt2, stage2, stats2, True, k2))
+                wl2.free()
+            except Exception as ex:
+                if rank == 0:
+                    out["tile_shard"] = {"error": repr(ex)[:300]}
+            watchdog.cancel()
+    side = None
+    if wl is not None:
+        scene, sdict, es, gy = wl.scene, wl.sdict, wl.es, wl.gy
+        fwd_only = wl.fwd_only
 
     if rank == 0:
-        if side is not None:
-            out[side_key] = side
-        if sharded and world > 1:
+        if sharded and world > 1 and out.get("scaling") == "strong":
             out["tile_shard_exchange"] = ("forward: every peer sends its strip as three channel segments straight into rank 0's frame (grouped RCCL send/recv); "
                                           "backward: all-reduce of 36 B per Gaussian between the two halves; the per-Gaussian stages run replicated "
                                           "(DESIGN.md section 7 gives the Amdahl ceiling per N)")

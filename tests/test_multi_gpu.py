@@ -45,3 +45,36 @@ def test_two_ranks_on_one_gpu_host_staged_exchange():
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL between them)")
 def test_two_ranks_two_gpus_rccl():
     _spawn("nccl")
+
+
+def _bench_two_ranks(extra):
+    """bench.py as the driver launches it for N = 2 (one process per rank, rendezvous on 127.0.0.1), in its one-GPU self-test mode
+    (`--test-one-gpu`: both ranks on cuda:0, gloo process group): exercises the N > 1 code path -- fallback measurement first, tile-row
+    headline under the watchdog, the JSON line -- on the 1-GPU box.  The numbers mean nothing; the shape of the line does."""
+    import json
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(conftest.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                                       "--test-one-gpu", "--scale", "0.1", "--probe-timeout", "240"] + extra,
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=900) for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[1][-2000:] for o in outs)
+    lines = [ln for ln in outs[0][0].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not any(ln.startswith("{") for ln in outs[1][0].splitlines())   # ONE line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_n2_tile_row_headline_with_frame_shard_side_object():
+    d = _bench_two_ranks([])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "tilerows2", d
+    assert d["rccl_ranks"]["world_size"] == 2 and d["rccl_ranks"]["all_reduce_of_ones"] == 2
+    assert d["value"] > 0 and d["frame_shard"]["scaling"] == "weak" and d["frame_shard"]["value"] > 0
+    assert "tile_shard" not in d   # (the error object of a tile-row exchange that hung or failed)
+
+
+def test_bench_n2_frames_headline_keeps_the_tile_row_side_object():
+    d = _bench_two_ranks(["--shard", "frames"])
+    assert d["scaling"] == "weak" and d["config"]["parallelism"] == "frames2" and d["tile_shard"]["scaling"] == "strong" and d["tile_shard"]["value"] > 0
