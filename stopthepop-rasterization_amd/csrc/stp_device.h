@@ -469,7 +469,7 @@ __device__ __forceinline__ uint32_t subtile_cull_mask(float4 co, float2 xy, int 
 {
     const float rcp_x = rcp_ieee(3.0f * 3.0f * co.x), rcp_y = rcp_ieee(3.0f * 3.0f * co.z);
     uint32_t mask = 0;
-#pragma unroll
+#pragma unroll 1
     for (int w = 0; w < 4; w++)
 #pragma unroll
         for (int sx = 0; sx < 4; sx++) {
