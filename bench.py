@@ -132,13 +132,14 @@ def profile_entry(kernel: str, workload: str):
 class Workload:
     """One BASELINE configuration resident in HBM: tensors, the drop-in rasterizer module, one step() = one pass of the hot path."""
 
-    def __init__(self, name, variant, dev, fwd_only=False, scale=1.0, dist=None, rank=0, world=1, sharded=False, train_forward_only=False):
+    def __init__(self, name, variant, dev, fwd_only=False, scale=1.0, dist=None, rank=0, world=1, sharded=False, train_forward_only=False, loss=False):
         import diff_gaussian_rasterization as dgr
         from diff_gaussian_rasterization import _C, scenes, tile_shard
         self.name, self.variant, self.dev = name, variant, dev
         self.fwd_only = fwd_only or name == "C4"
         self.scale, self.world, self.sharded = scale, world, sharded
         self.train_forward_only = train_forward_only
+        self.loss = loss   # True: the step also holds torch's kernels of a weighted-sum loss (the round-1/2 definition of a step)
         self._C = _C
         self.scene = scene = scenes.config(name, scale=scale)
         self.es = es = settings_for(variant, name)
@@ -170,7 +171,10 @@ class Workload:
         color, radii = self.raster(self.means3D, self.means2D, self.opac, shs=self.shs, scales=self.scales, rotations=self.rots)
         self.state["color"], self.state["radii"] = color, radii
         if not self.fwd_only and not self.train_forward_only:
-            (color * self.w_img).sum().backward()
+            if self.loss:
+                (color * self.w_img).sum().backward()   # + three torch kernels (mul, sum, mul): about 0.06 ms at 1080p, none of them the hot path
+            else:
+                color.backward(self.w_img)               # dL/dimage is resident in HBM like every other input of the step
         elif self.train_forward_only:  # nobody will replay this log: hand the buffers back
             self._C.release_scratch(color.grad_fn.saved_tensors[11]); self._C.release_scratch(color.grad_fn.saved_tensors[10])
 
@@ -378,6 +382,9 @@ def main():
     ap.add_argument("--probe-timeout", type=float, default=120.0, help="seconds the side measurement may take before the headline is printed without it")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; invalidates the headline number)")
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--with-loss", action="store_true",
+                    help="the step also computes a weighted-sum loss with torch ((image * w).sum().backward(), the step of rounds 1-2) instead of "
+                         "handing dL/dimage, resident in HBM, to the rasterizer's backward")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps (device clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="N == 1: leave out the other_workloads object (C2-min, C3, C4 on one GPU, C5; 10 steps each)")
@@ -439,7 +446,7 @@ def main():
     def measure(shard_rows, steps, warmup, prewarm):
         """One Workload + one timed region (contract: W warm-up steps, EXACTLY K steps between barrier + synchronise, MAX over ranks)."""
         w = Workload(args.workload, args.variant, dev, fwd_only=fwd_only, scale=args.scale, dist=dist, rank=rank, world=world,
-                     sharded=shard_rows, train_forward_only=args.train_forward_only)
+                     sharded=shard_rows, train_forward_only=args.train_forward_only, loss=args.with_loss)
         dt_, stage_, stats_, cum_ = timed_region(w, steps, warmup, prewarm, barrier, per_step=args.per_step)
         if args.per_step and rank == 0:
             print("cumulative ms after each step:", cum_, "reserved GB:", round(torch.cuda.memory_reserved(dev) / 2**30, 2),
@@ -470,7 +477,10 @@ def main():
                                    f"{'fwd' if w.fwd_only else 'fwd+bwd'}",
                        "P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B,
                        "parallelism": (f"tilerows{world}" if shard_rows else f"frames{world}") if world > 1 else "single",
-                       "scale": args.scale},
+                       "scale": args.scale,
+                       "step": ("rasterizer forward" if w.fwd_only else
+                                "rasterizer forward + torch weighted-sum loss + backward ((image * w).sum().backward())" if w.loss else
+                                "rasterizer forward + backward; dL/dimage resident in HBM like the other inputs (image.backward(dL_dimage))")},
             "step_ms": step_stats,
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "algorithmic_bytes": {"forward": int(info["fwd_bytes"]), "backward": int(info["bwd_bytes"]), "model": "SURVEY.md section 8(d)"},
@@ -576,6 +586,14 @@ def main():
             out.update(checker)
         if world == 1 and not args.no_other_workloads and args.workload == "C2" and args.variant == "full" and args.scale == 1.0 \
                 and not args.fwd_only and not args.train_forward_only:
+            if not wl.loss:
+                # the same workload with the step definition of rounds 1-2 (a torch loss inside the step), for continuity
+                wl.loss = True
+                k3 = max(1, min(args.steps, 20))
+                dt3, stage3, stats3, _ = timed_region(wl, k3, 3, 0.0, barrier)
+                out["with_torch_loss"] = {"value": round(k3 / dt3, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * dt3 / k3, 4), "steps": k3,
+                                          "step_ms": stats3, "what": "the same workload with (image * w).sum().backward() as the step: three torch "
+                                          "kernels (mul, sum, mul) inside the timed region, as in rounds 1-2"}
             wl.free()
             _C.clear_scratch_pool(dev)
             torch.cuda.empty_cache()

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Bitwise comparison of two builds of the library on one frame (GPU box): tile lists, image, final_T, per-pixel blend counts and the
-whole blend log -- what "the kernel work changed nothing" means.   usage: tools/compare_builds.py <libA.so> <libB.so> [workload] [variant]"""
+whole blend log -- what "the kernel work changed nothing" means.   usage: tools/compare_builds.py <libA.so> <libB.so> [workload] [variant] [NAME=VALUE ...]
+(NAME=VALUE: environment switches set just before library B is loaded -- the library reads its switches once, at its first forward)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "stopthepop-rasterization_amd")); sys.path.insert(0, ROOT)
@@ -21,6 +22,9 @@ args = (t(sc.bg), t(sc.means3D), empty, t(sc.opacities), t(sc.scales), t(sc.rota
         t(sc.inv_viewprojmatrix), sc.tanfovx, sc.tanfovy, sc.H, sc.W, t(sc.shs), 3, t(sc.campos), False, sd, False, False)
 out = {}
 for name, lib in (("A", libA), ("B", libB)):
+    if name == "B":
+        for kv in sys.argv[5:]:
+            os.environ[kv.split("=", 1)[0]] = kv.split("=", 1)[1]
     _C.use_library(lib)
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
     torch.cuda.synchronize()
