@@ -88,6 +88,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.bin_generation = _C.scratch_generation(binningBuffer)
         ctx.save_for_backward(colors_precomp, means3D, opacities, scales, rotations, cov3Ds_precomp, radii, sh, color,
                               geomBuffer, binningBuffer, imgBuffer)
+        # radii is an integer output: without these two lines autograd materialises a (P,) zero "gradient" for it in
+        # every backward (a 4 MB fill kernel per step at 1 M Gaussians)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
@@ -98,6 +102,8 @@ class _RasterizeGaussians(torch.autograd.Function):
          binningBuffer, imgBuffer) = ctx.saved_tensors
         _C.check_scratch(imgBuffer, ctx.img_generation)
         _C.check_scratch(binningBuffer, ctx.bin_generation)
+        if grad_out_color is None:  # (set_materialize_grads(False): cannot happen while the image is the only differentiable output)
+            grad_out_color = torch.zeros_like(color)
         # positional layout of _C.rasterize_gaussians_backward (25 arguments)
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
