@@ -205,18 +205,23 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
         while time.perf_counter() - t_pre < prewarm_seconds:
             wl.step()
             torch.cuda.synchronize(dev)
-    for _ in range(warmup):
-        wl.step()
-    barrier()
+    # Everything that takes host time without GPU work happens BEFORE the warm-up steps, so that the timed region follows the warm-up with
+    # nothing but the contract's barrier + synchronise in between: a gap of tens of milliseconds there (a gc pass, 512 + K hipEvent
+    # creations) lets the device fall back to its idle clocks, and the first ten timed steps then measure the ramp (seen with --per-step:
+    # 2.89, 2.73, 2.67, 2.65, ... 2.50 ms).
     import gc
     gc.collect()
     gc.disable()  # (a collection inside the timed region is a multi-millisecond stall of the launching thread)
-    _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
+    _C.timing_enable(True)   # creates the stage timer's hipEvents (once per device) ...
+    _C.timing_enable(False)  # ... and is switched on for real right before the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     stream = torch.cuda.current_stream(dev)
     for m in marks:   # torch creates the hipEvent at the first record(): do that HERE, not inside the timed region
         m.record(stream)
-    torch.cuda.synchronize(dev)
+    for _ in range(warmup):
+        wl.step()
+    barrier()
+    _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
     t0 = time.perf_counter()
     marks[0].record(stream)
     cum = []
