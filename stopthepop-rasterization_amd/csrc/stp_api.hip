@@ -251,7 +251,7 @@ using namespace stp;
 namespace {
 // (`done`: recorded on the side stream behind this forward's SH -> RGB kernel -- one per slot, so that concurrent forwards
 // on one device do not re-record each other's event)
-struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev = nullptr; hipEvent_t done = nullptr; int device = 0; };
+struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev = nullptr; hipEvent_t done = nullptr; int device = 0; uint32_t ticket = 0; };
 constexpr int MAX_DEVICES = 32, MAILBOX_RING = 8;
 struct MailboxRing { Mailbox slot[MAILBOX_RING]; std::atomic<unsigned> next{0}; std::atomic<bool> ready{false}; };
 MailboxRing g_mailboxes[MAX_DEVICES];
@@ -310,7 +310,7 @@ int acquire_mailbox(Mailbox* out)
         if (!ring.ready.load(std::memory_order_relaxed)) {
             for (int i = 0; i < MAILBOX_RING; i++) {
                 void* h = nullptr; void* d = nullptr;
-                if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess ||
+                if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer(&d, h, 0) != hipSuccess ||
                     hipEventCreateWithFlags(&ring.slot[i].ev, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&ring.slot[i].done, hipEventDisableTiming) != hipSuccess)
                     return fail(STP_ERR_HIP, "cannot create the num_rendered mailbox");
@@ -321,7 +321,9 @@ int acquire_mailbox(Mailbox* out)
             ring.ready.store(true, std::memory_order_release);
         }
     }
-    *out = ring.slot[ring.next.fetch_add(1u) % MAILBOX_RING];
+    const unsigned seq = ring.next.fetch_add(1u);
+    *out = ring.slot[seq % MAILBOX_RING];
+    out->ticket = seq + 1u == 0u ? 1u : seq + 1u; // what the kernel writes LAST into the slot's third word: unique per use of the slot
     return 0;
 }
 } // namespace
@@ -512,7 +514,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // the GPU keeps working while the host wakes up, sizes the buffer and launches duplicate / sort.
     Mailbox mb;
     if (int rc = acquire_mailbox(&mb)) return rc;
-    STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, st), "mailbox launch");
+    STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, mb.ticket, st), "mailbox launch");
     STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
     SideStream* const side = side_stream(mb.device);
     SideJoin colours{mb.done, st, false};
@@ -543,7 +545,24 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         bin_ptr = (char*)binning_alloc(binning_user, bin_have);
         if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
     }
-    STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");
+    // The host watches the slot itself: the kernel's last store (the ticket) is visible a microsecond after it was made, the event behind the
+    // kernel is signalled by a barrier packet some microseconds later, and hipEventSynchronize's wake-up adds its own.  The event is still
+    // polled now and then: it completes if the kernel has, and it is how a device fault surfaces (STP_MAILBOX=event: wait on the event only).
+    static const char* const mbx_env = std::getenv("STP_MAILBOX");
+    static const bool mbx_spin = !(mbx_env && std::strcmp(mbx_env, "event") == 0);
+    if (mbx_spin) {
+        for (unsigned it = 1;; it++) {
+            if (mb.host[2] == mb.ticket) break;
+            if ((it & 255u) == 0u) {
+                const hipError_t q = hipEventQuery(mb.ev);
+                if (q == hipSuccess) break;
+                if (q != hipErrorNotReady) return fail_hip(q, "query (num_rendered)");
+                if (it > (1u << 22)) { STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)"); break; } // (seconds of spinning: stop burning a core)
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");
     const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
     if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
     f.wild_cov = (host_status[1] & 2u) ? 1 : 0;

@@ -161,7 +161,7 @@ hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* 
 hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int T, bool with_log, bool tile_counters, hipStream_t st); // status, ranges, tile flags (+ tile counters)
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
-hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, hipStream_t st);
+hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st);
 hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);

@@ -597,16 +597,18 @@ hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const i
 }
 
 // num_rendered (the scan's last element) and the status word into host-mapped memory: the forward's one host hand-over
-__global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const uint32_t* __restrict__ status, volatile uint32_t* mailbox)
+__global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const uint32_t* __restrict__ status, volatile uint32_t* mailbox, uint32_t ticket)
 {
     mailbox[0] = *last_offset;
     mailbox[1] = *status;
     __threadfence_system();
+    mailbox[2] = ticket; // the host may be watching this word (stp_forward): it goes out after the two values
+    __threadfence_system();
 }
 
-hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, hipStream_t st)
+hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st)
 {
-    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, last_offset, status, mailbox_dev);
+    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, last_offset, status, mailbox_dev, ticket);
     return hipGetLastError();
 }
 
