@@ -16,9 +16,10 @@
 // acc[term][position - window start], 512 positions = 36 KB.  A tile whose list fits (all of C2-full) is one window:
 // a blend is nine ds_add_u64 and nothing else, the sums leave the chip once at the end (16-lane group = one position,
 // nine lanes = nine sums, one atomic instruction into the Gaussian's 64-byte gradient record).  Longer lists are
-// walked window by window: a lane pauses at its first record beyond the window, the workgroup meets at a barrier,
-// writes the window out and moves on -- every pixel visits the list in (nearly) increasing position, so only the
-// few records that the re-sort moved across a window boundary fall back to global atomics.  Before the LDS adds,
+// walked with a window that slides in half steps (position p lives in slot p mod 512): a lane pauses at its first
+// record beyond the window, and when every lane has left the window's lower half the workgroup meets at a barrier,
+// writes that half out and moves on -- every pixel visits the list in (nearly) increasing position, so only the
+// few records that the re-sort moved behind the window fall back to global atomics.  Before the LDS adds,
 // lanes that hold the same position merge their terms pairwise with DPP (the adds serialise on equal addresses).
 #include "stp_internal.h"
 #include "stp_blend.h"
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #if STP_REPLAY_F64
             if (cur_pos >= lo) { // nine ds_add_f64, nothing else (one v_cvt per term; no range check, no fixed-point scale)
 #pragma unroll
-                for (int kk = 0; kk < 9; kk++) atomicAdd(&s_accd[kk * WINDOW + (cur_pos - lo)], (double)g[kk]);
+                for (int kk = 0; kk < 9; kk++) atomicAdd(&s_accd[kk * WINDOW + (cur_pos & (WINDOW - 1))], (double)g[kk]);
             } else {
 #else
             float gmax = fabsf(g[0]);
@@ -225,14 +226,14 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             if (cur_pos >= lo && gmax < fx_cap) { // nine adds, nothing else
 #if STP_REPLAY_COLOR32
 #pragma unroll
-                for (int kk = 0; kk < 3; kk++) atomicAdd(&s_acc32[kk * WINDOW + (cur_pos - lo)], (unsigned int)__float2int_rn(g[kk] * fx_scale32));
+                for (int kk = 0; kk < 3; kk++) atomicAdd(&s_acc32[kk * WINDOW + (cur_pos & (WINDOW - 1))], (unsigned int)__float2int_rn(g[kk] * fx_scale32));
 #endif
 #pragma unroll
                 for (int kk = ACC64_FIRST; kk < 9; kk++) {
                     // round-to-nearest integer of g*scale through the 1.5*2^52 trick (|g*scale| < 2^51 + margin)
                     const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
                     const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
-                    atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + (cur_pos - lo)], (unsigned long long)qv);
+                    atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + (cur_pos & (WINDOW - 1))], (unsigned long long)qv);
                 }
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
 #endif
@@ -243,16 +244,18 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     };
     // the window's sums leave the chip: 16-lane group = one position, nine lanes = its nine sums, one atomic
     // instruction (one request) into the Gaussian's 64-byte gradient record
-    auto flush_window = [&](int lo) __attribute__((always_inline)) {
+    // (positions f0 .. f1 - 1, at most WINDOW of them; position p lives in slot p mod WINDOW)
+    auto flush_range = [&](int f0, int f1) __attribute__((always_inline)) {
         __syncthreads();
-        const int term = lane & 15, cnt = min(WINDOW, list_len - lo);
-        for (int p = (int)(threadIdx.x >> 4); p < cnt; p += 16) {
+        const int term = lane & 15;
+        for (int pp = f0 + (int)(threadIdx.x >> 4); pp < f1; pp += 16) {
+            const int p = pp & (WINDOW - 1);
             if (term < 9) {
 #if STP_REPLAY_F64
                 const double v = s_accd[term * WINDOW + p];
                 if (v != 0.0) {
                     s_accd[term * WINDOW + p] = 0.0;
-                    atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)v);
+                    atomicAdd(grad_slot(a, __float_as_int(eC[pp].w), term), (float)v);
                 }
 #else
 #if STP_REPLAY_COLOR32
@@ -260,7 +263,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                     const int v32 = (int)s_acc32[term * WINDOW + p];
                     if (v32 != 0) {
                         s_acc32[term * WINDOW + p] = 0u;
-                        atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)v32 * fx_inv32);
+                        atomicAdd(grad_slot(a, __float_as_int(eC[pp].w), term), (float)v32 * fx_inv32);
                     }
                     continue;
                 }
@@ -269,7 +272,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 if (STP_REPLAY_COPIES == 2) { v += (long long)s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p]; s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p] = 0ull; }
                 if (v != 0) {
                     s_acc[(term - ACC64_FIRST) * WINDOW + p] = 0ull;
-                    atomicAdd(grad_slot(a, __float_as_int(eC[lo + p].w), term), (float)((double)v * fx_inv));
+                    atomicAdd(grad_slot(a, __float_as_int(eC[pp].w), term), (float)((double)v * fx_inv));
                 }
 #endif
             }
@@ -344,28 +347,42 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             if (have && !ok) n = kr; // (an ulp of difference against the forward's transmittance: stop where it says so)
             merge_and_add(ok, cur_pos, cur_id, g, 0, dense);
         }
-        flush_window(0);
+        flush_range(0, list_len);
     } else {
     // ---- longer lists, window by window: every lane pauses at its first record beyond the window ----
     int k = 0; // records consumed by this lane
     int pos = (0 < n) ? log_at(0) : EXHAUSTED;
     int pos1 = (1 < n) ? log_at(1) : EXHAUSTED;
     Entry en = entry_at(pos);
-    const int n_win = (list_len + WINDOW - 1) / WINDOW; // workgroup-uniform
 #ifndef STP_REPLAY_DEPHASE_WIN
 #define STP_REPLAY_DEPHASE_WIN 0
 #endif
-    // De-phasing as in the one-window walk (lane x of every 16-lane row sits out the first x iterations of each window, because
-    // the lanes re-align at every window's end) was built and MEASURED SLOWER in round 3: C2-min replay 1.015 -> 1.06 ms, C3
-    // 1.74 -> 2.08 ms, C5 1.72 -> 1.97 ms (one box, alternating) -- the 15 extra iterations are paid per WINDOW and per wave,
-    // and a window's stragglers already spread the lanes.  Kept as a switch, off.
+#ifndef STP_REPLAY_RING
+#define STP_REPLAY_RING 1
+#endif
+    // De-phasing as in the one-window walk (lane x of every 16-lane row sits out the first x iterations) was built and MEASURED SLOWER
+    // in round 3, twice: with hard windows, once per window (C2-min replay 1.015 -> 1.06 ms, C3 1.74 -> 2.08, C5 1.72 -> 1.97), and with
+    // the sliding window, once at the start (C2-min 1.007 -> 1.016 ms, C3 1.65 -> 1.90, C5 1.65 -> 1.86; one box, alternating).  Kept as
+    // a switch, off.
     const int dephase = (STP_REPLAY_DEPHASE_WIN && !same_start) ? x : 0;
-    for (int win = 0; win < n_win; win++) {
-        const int lo = win * WINDOW, hi = lo + WINDOW;
-        int wait = dephase;
+    // The window slides in HALF steps (STP_REPLAY_RING): a phase covers positions [lo, lo + WINDOW), position p lives in slot p mod WINDOW,
+    // and the phase ends when every lane has left its LOWER half -- lanes that are ahead keep blending in the upper half meanwhile and
+    // stop only at lo + WINDOW.  Then the lower half's sums leave the chip and its slots become the next phase's upper half.  With hard
+    // windows (STEP = WINDOW, round 2) every lane idled from its last record of a window until the slowest lane of the slowest wave had
+    // finished it: the iterations of a wave were the SUM over the windows of the busiest pixel's records in each.
+    // MEASURED (round 3, one box, alternating, -DSTP_REPLAY_RING=0 = hard windows): C3 replay 1.734 -> 1.645 ms, C5 1.714 -> 1.636,
+    // C2-min 1.010 -> 1.005, L1 2.856 -> 2.836; C2-full (one window per tile) unchanged.
+    constexpr int STEP = STP_REPLAY_RING ? WINDOW / 2 : WINDOW;
+    static_assert((WINDOW & (WINDOW - 1)) == 0, "slots are addressed by position mod WINDOW");
+    int wait = dephase; // (sliding window: the lanes are not re-aligned at a phase's end, one offset at the start lasts)
+    for (int lo = 0;; lo += STEP) {
+        const int hi = lo + WINDOW;
+        const bool last = hi >= list_len;                  // (workgroup-uniform)
+        const int leave = last ? EXHAUSTED : lo + STEP;    // the phase is over when every lane's next record is at or beyond this position
+        if (!STP_REPLAY_RING) wait = dephase;
         for (;;) {
-            const bool mine = pos < hi; // my next record belongs to this window (or to an earlier one: a straggler)
-            if (!__any(mine)) break;
+            if (!__any(pos < leave)) break;
+            const bool mine = pos < hi; // my next record belongs to this phase (or to an earlier one: a straggler)
             const bool act = mine && wait <= 0;
             wait--;
             const Entry cur = en;
@@ -383,8 +400,9 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             if (act && !ok) { n = k; pos = EXHAUSTED; pos1 = EXHAUSTED; } // (saturated one record earlier than the forward said)
             merge_and_add(ok, cur_pos, cur_id, g, lo, same_start);
         }
-        flush_window(lo);
-        if (win + 1 < n_win) __syncthreads();
+        flush_range(lo, last ? list_len : lo + STEP);
+        if (last) break;
+        __syncthreads();
     }
     }
 }
