@@ -372,7 +372,11 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     // finished it: the iterations of a wave were the SUM over the windows of the busiest pixel's records in each.
     // MEASURED (round 3, one box, alternating, -DSTP_REPLAY_RING=0 = hard windows): C3 replay 1.734 -> 1.645 ms, C5 1.714 -> 1.636,
     // C2-min 1.010 -> 1.005, L1 2.856 -> 2.836; C2-full (one window per tile) unchanged.
-    constexpr int STEP = STP_REPLAY_RING ? WINDOW / 2 : WINDOW;
+#ifndef STP_REPLAY_RING_DIV
+#define STP_REPLAY_RING_DIV 2 // steps of WINDOW / 2.  Quarter / eighth steps (more, smaller flushes and barriers): C3 replay 1.655 -> 1.669 / 1.708 ms,
+                              // C5 1.637 -> 1.694 / 1.752
+#endif
+    constexpr int STEP = STP_REPLAY_RING ? WINDOW / STP_REPLAY_RING_DIV : WINDOW;
     static_assert((WINDOW & (WINDOW - 1)) == 0, "slots are addressed by position mod WINDOW");
     int wait = dephase; // (sliding window: the lanes are not re-aligned at a phase's end, one offset at the start lasts)
     for (int lo = 0;; lo += STEP) {
