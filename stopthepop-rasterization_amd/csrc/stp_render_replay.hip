@@ -64,6 +64,9 @@ namespace {
 #ifndef STP_REPLAY_WINDOW
 #define STP_REPLAY_WINDOW 512
 #endif
+#ifndef STP_REPLAY_STRAIGHT
+#define STP_REPLAY_STRAIGHT 1 // the gradient terms of a step as straight-line code (see blend_terms); 0: the branchy form of rounds 1-3
+#endif
 constexpr int WINDOW = STP_REPLAY_WINDOW; // list positions per window (9 x 512 x 8 B = 36 KB of LDS: four workgroups per CU)
 constexpr int EXHAUSTED = 0x7fffffff; // "position" of a lane that has no record left
 
@@ -154,6 +157,47 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 
     // the gradient terms of one record (reference maths); false = nothing to add (no record, or the pixel saturates here)
     auto blend_terms = [&](bool act, const Entry& cur, float (&g)[9]) __attribute__((always_inline)) -> bool {
+#if STP_REPLAY_STRAIGHT
+        // Straight-line form: every lane evaluates its (possibly stand-in) entry; a lane without a record, or whose pixel saturates
+        // here, is switched off through its FACTORS -- all nine terms are linear in (T, T_final), so T := 0 and T_final := 0 make them
+        // exact zeros (every other factor is finite: alpha <= 0.99, test_T >= 1e-6 where it is used, the stand-in is entry 0 of the
+        // list) -- three selects instead of two branches and eighteen zeroing moves per step.
+        {
+            const float4 co = cur.d;
+            const float dx = cur.c.y - pxf, dy = cur.c.z - pyf;
+            const float G = exp_blend(fminf(blend_power(dx, dy, co), 0.0f)); // (a recorded blend has power <= 0: the clamp only keeps a stand-in's G finite)
+            const float alpha = fminf(0.99f, co.w * G);
+            const float test_T = bp.T * (1.0f - alpha);
+            const bool ok = act && !(test_T < T_THRESHOLD);
+            const float Tm = ok ? bp.T : 0.0f, tfm = ok ? bp.T_final : 0.0f;
+            const float dchannel_dcolor = alpha * Tm;
+            const float rcp_test_T = __builtin_amdgcn_rcpf(test_T);
+            const float rcp_1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+            const float col[3] = {cur.f.x, cur.f.y, cur.f.z};
+            float dL_dalpha = 0.0f;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                bp.C[ch] += col[ch] * alpha * Tm;
+                const float accum_rec = (bp.final_color[ch] - bp.C[ch]) * rcp_test_T;
+                dL_dalpha += (col[ch] - accum_rec) * bp.dL_dpix[ch];
+                g[ch] = dchannel_dcolor * bp.dL_dpix[ch];
+            }
+            dL_dalpha *= Tm;
+            dL_dalpha += (-tfm * rcp_1ma) * bp.bg_dot;
+            const float dL_dG = co.w * dL_dalpha;
+            const float gdx = G * dx, gdy = G * dy;
+            const float dG_ddelx = -gdx * co.x - gdy * co.y;
+            const float dG_ddely = -gdy * co.z - gdx * co.y;
+            g[3] = dL_dG * dG_ddelx * (0.5f * (float)a.W);
+            g[4] = dL_dG * dG_ddely * (0.5f * (float)a.H);
+            g[5] = -0.5f * gdx * dx * dL_dG;
+            g[6] = -0.5f * gdx * dy * dL_dG;
+            g[7] = -0.5f * gdy * dy * dL_dG;
+            g[8] = G * dL_dalpha;
+            bp.T = ok ? test_T : bp.T;
+            return ok;
+        }
+#endif
         bool ok = false;
         if (act) {
             FrontData fd;
@@ -337,10 +381,15 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             // issue the next round of loads before touching this step's data
             en = entry_at(max(pos1, 0));
+#if STP_REPLAY_STRAIGHT
+            const int rec2 = log_at((uint32_t)min(max(kr + 2, 0), BLEND_LOG_DEPTH - 1)); // (unconditional: a row of the log that holds no record of mine is readable garbage)
+            const int pos2 = (kr + 2 >= 0 && kr + 2 < n) ? rec2 : -1;
+#else
             const int pos2 = (kr + 2 >= 0 && kr + 2 < n) ? log_at((uint32_t)(kr + 2)) : -1;
+#endif
             pos = pos1;
             pos1 = pos2;
-#if !STP_REPLAY_HOIST
+#if !STP_REPLAY_HOIST && !STP_REPLAY_STRAIGHT
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
 #endif
             const bool ok = blend_terms(have, cur, g);
@@ -397,7 +446,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             pos = act ? pos1 : pos;
             pos1 = act ? (k + 1 < n ? rec : EXHAUSTED) : pos1;
             en = entry_at(pos);
-#if !STP_REPLAY_HOIST
+#if !STP_REPLAY_HOIST && !STP_REPLAY_STRAIGHT
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
 #endif
             const bool ok = blend_terms(act, cur, g);
