@@ -371,31 +371,46 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             for (int o = 32; o > 0; o >>= 1) nn = max(nn, __shfl_xor(nn, o));
             nmax = nn;
         }
-        int kk0 = -off; // my record index in iteration 0
-        int pos = (0 < n && off == 0) ? log_at(0) : -1, pos1 = (1 - off >= 0 && 1 - off < n) ? log_at((uint32_t)(1 - off)) : -1;
+        // Pipeline: `pos` = list position of my record of this step (-1: none), `raw1` = the log word of the record after it, read a step
+        // ago and checked against the record count only now (a count can still shrink, see below); the entry of the NEXT step is
+        // requested at the top of a step, the log word of the one after next right behind it -- unconditionally (a row of the log that
+        // holds no record of mine is readable garbage): nothing in a step waits for a load issued in the same step.
+        int pos = (0 < n && off == 0) ? log_at(0) : -1;
+        int raw1 = log_at((uint32_t)min(max(1 - off, 0), BLEND_LOG_DEPTH - 1));
         Entry en = entry_at(max(pos, 0));
-        for (int k = 0; k < nmax; k++) {
+#ifndef STP_REPLAY_UNROLL2
+#define STP_REPLAY_UNROLL2 1 // two copies of the step, the entry registers alternating between them (no copy of the ten entry words at the back edge)
+#endif
+        // one step: blends `cur` (loaded an iteration ago), loads the entry of the next step into `nxt`
+        auto one_step = [&](const int k, const Entry& cur, Entry& nxt) __attribute__((always_inline)) {
             const int kr = k - off; // my record index
             const bool have = kr >= 0 && kr < n;
-            const Entry cur = en;
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
-            // issue the next round of loads before touching this step's data
-            en = entry_at(max(pos1, 0));
-#if STP_REPLAY_STRAIGHT
-            const int rec2 = log_at((uint32_t)min(max(kr + 2, 0), BLEND_LOG_DEPTH - 1)); // (unconditional: a row of the log that holds no record of mine is readable garbage)
-            const int pos2 = (kr + 2 >= 0 && kr + 2 < n) ? rec2 : -1;
-#else
-            const int pos2 = (kr + 2 >= 0 && kr + 2 < n) ? log_at((uint32_t)(kr + 2)) : -1;
-#endif
+            const int pos1 = (kr + 1 >= 0 && kr + 1 < n) ? raw1 : -1;
+            nxt = entry_at(max(pos1, 0));
+            raw1 = log_at((uint32_t)min(max(kr + 2, 0), BLEND_LOG_DEPTH - 1));
             pos = pos1;
-            pos1 = pos2;
 #if !STP_REPLAY_HOIST && !STP_REPLAY_STRAIGHT
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
 #endif
             const bool ok = blend_terms(have, cur, g);
-            if (have && !ok) n = kr; // (an ulp of difference against the forward's transmittance: stop where it says so)
+            if (have && !ok) { n = kr; pos = -1; } // (an ulp of difference against the forward's transmittance: stop where it says so)
             merge_and_add(ok, cur_pos, cur_id, g, 0, dense);
+        };
+#if STP_REPLAY_UNROLL2
+        Entry en2 = en;
+#pragma unroll 1
+        for (int k = 0; k < nmax; k += 2) {
+            one_step(k, en, en2);
+            if (k + 1 >= nmax) break;
+            one_step(k + 1, en2, en);
         }
+#else
+        for (int k = 0; k < nmax; k++) {
+            const Entry cur = en;
+            one_step(k, cur, en);
+        }
+#endif
         flush_range(0, list_len);
     } else {
     // ---- longer lists, window by window: every lane pauses at its first record beyond the window ----
