@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 const float mf = (match && (LOWER)) ? 1.0f : 0.0f;                                                  \
                 dpp_hazard_guard(); /* g[] was written by ordinary VALU instructions a moment ago */                \
                 _Pragma("unroll") for (int kk = 0; kk < 9; kk++) g[kk] = partner_fma<CTRL>(g[kk], mf, g[kk]);       \
-                if (match && !(LOWER)) { ok = false; key = -2 - lane; }                                             \
+                if (match && !(LOWER)) key = -2 - lane; /* the upper lane of a matching pair has handed its terms over */ \
             }
             STP_MERGE_LEVEL(0xB1, (q & 1) == 0) // partner lane ^ 1 (quad_perm [1,0,3,2])
             STP_MERGE_LEVEL(0x4E, (q & 2) == 0) // partner lane ^ 2 (quad_perm [2,3,0,1])
@@ -238,6 +238,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 STP_MERGE_LEVEL(0x140, x < 8)        // partner 15 - i inside the 16-lane row (row_mirror)
             }
 #undef STP_MERGE_LEVEL
+            ok = key >= 0; // (a lane that blends holds a list position, every other one its negative stand-in: no separate flag to carry through the levels)
         }
 #endif
 #ifdef STP_REPLAY_STATS
