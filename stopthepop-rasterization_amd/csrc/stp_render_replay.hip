@@ -155,6 +155,13 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         return Entry{at(eC), at(eD), at(eF)};
     };
 
+    const uint32_t list_last = (uint32_t)(list_len - 1);
+    auto entry_at_clamped = [&](uint32_t p) __attribute__((always_inline)) { // (p beyond the list -- a corrupt log word -- reads the last entry)
+        const uint32_t off = min(p, list_last) << 4;
+        auto at = [&](const float4* base) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off); };
+        return Entry{at(eC), at(eD), at(eF)};
+    };
+
     // the gradient terms of one record (reference maths); false = nothing to add (no record, or the pixel saturates here)
     auto blend_terms = [&](bool act, const Entry& cur, float (&g)[9]) __attribute__((always_inline)) -> bool {
 #if STP_REPLAY_STRAIGHT
@@ -385,11 +392,15 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         // one step: blends `cur` (loaded an iteration ago), loads the entry of the next step into `nxt`
         auto one_step = [&](const int k, const Entry& cur, Entry& nxt) __attribute__((always_inline)) {
             const int kr = k - off; // my record index
-            const bool have = kr >= 0 && kr < n;
+            // (index checks as one unsigned compare each -- n >= 0; the entry offset clamped with one unsigned minimum; the log row of a
+            // record index outside 0 .. 255 wraps to some other row of my slice, whose word is read and never used)
+            const bool have = (uint32_t)kr < (uint32_t)n;
+            const bool have1 = (uint32_t)(kr + 1) < (uint32_t)n;
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
-            const int pos1 = (kr + 1 >= 0 && kr + 1 < n) ? raw1 : -1;
-            nxt = entry_at(max(pos1, 0));
-            raw1 = log_at((uint32_t)min(max(kr + 2, 0), BLEND_LOG_DEPTH - 1));
+            const int pos1 = have1 ? raw1 : -1;
+            nxt = entry_at_clamped(have1 ? (uint32_t)raw1 : 0u);
+            static_assert((BLEND_LOG_DEPTH & (BLEND_LOG_DEPTH - 1)) == 0, "log rows are addressed modulo the depth");
+            raw1 = log_at((uint32_t)(kr + 2) & (uint32_t)(BLEND_LOG_DEPTH - 1));
             pos = pos1;
 #if !STP_REPLAY_HOIST && !STP_REPLAY_STRAIGHT
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
