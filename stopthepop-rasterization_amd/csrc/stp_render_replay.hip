@@ -58,11 +58,17 @@ namespace {
                              // six geometric ones stay 64-bit.  MEASURED (round 3, one box, alternating): C2-full 0.947 against 0.928 ms,
                              // C2-min 1.056 against 1.008, C3 1.87 against 1.72 -- no faster anywhere; kept as a switch for the record.
 #endif
+#if STP_REPLAY_FOLD && (STP_REPLAY_F64 || STP_REPLAY_COLOR32 || !STP_REPLAY_STRAIGHT)
+#error "STP_REPLAY_FOLD is written for the 64-bit fixed-point sums of the straight-line step"
+#endif
 #if STP_REPLAY_COLOR32 && STP_REPLAY_F64
 #error "STP_REPLAY_F64 keeps all nine sums as doubles"
 #endif
 #ifndef STP_REPLAY_WINDOW
 #define STP_REPLAY_WINDOW 512
+#endif
+#ifndef STP_REPLAY_FOLD
+#define STP_REPLAY_FOLD 1 // constant factors of the geometric terms applied to the sums at the flush instead of to every pair (needs STP_REPLAY_STRAIGHT)
 #endif
 #ifndef STP_REPLAY_STRAIGHT
 #define STP_REPLAY_STRAIGHT 1 // the gradient terms of a step as straight-line code (see blend_terms); 0: the branchy form of rounds 1-3
@@ -124,6 +130,15 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     const bool md_ok = md > 0.0f && md < 3.0e38f;
     if (md_ok) (void)frexpf(md, &md_exp);
     const double fx_scale = ldexp(1.0, 31 - md_exp), fx_inv = ldexp(1.0, md_exp - 31);
+    // factor of term k that the blend step leaves out (STP_REPLAY_FOLD): applied once per sum
+    auto term_scale = [&](int k) __attribute__((always_inline)) -> float {
+#if STP_REPLAY_FOLD && STP_REPLAY_STRAIGHT
+        return k == 3 ? -0.5f * (float)a.W : k == 4 ? -0.5f * (float)a.H : (k >= 5 && k <= 7) ? -0.5f : 1.0f;
+#else
+        return 1.0f;
+#endif
+    };
+    const double fx_inv_term = fx_inv * (double)term_scale(lane & 15); // (flush: lane & 15 is the term a lane writes back)
     const float fx_cap = (md_ok || md == 0.0f) ? ldexpf(1.0f, min(md_exp + 20, 126)) : 0.0f; // (a tile whose M is not finite: nothing fits, every term goes to memory)
     // Colour terms: |alpha T dL/dpixel| < M = 2^md_exp by construction (M >= max |dL/dpixel| of the tile), and a lane that the
     // DPP merge has loaded with its partners' terms carries at most 16 of them: round(t 2^22 / M) fits 27 bits, the sum over
@@ -193,6 +208,16 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             dL_dalpha += (-tfm * rcp_1ma) * bp.bg_dot;
             const float dL_dG = co.w * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
+#if STP_REPLAY_FOLD
+            // the frame's constant factors of the five geometric terms (-W/2, -H/2, -1/2 three times) are applied to the SUMS when they
+            // leave the chip (term_scale), not to every pair: with u = G dx dL/dG, v = G dy dL/dG the five terms are eleven instructions
+            const float u = gdx * dL_dG, v = gdy * dL_dG;
+            g[3] = fmaf(v, co.y, u * co.x);
+            g[4] = fmaf(u, co.y, v * co.z);
+            g[5] = u * dx;
+            g[6] = u * dy;
+            g[7] = v * dy;
+#else
             const float dG_ddelx = -gdx * co.x - gdy * co.y;
             const float dG_ddely = -gdy * co.z - gdx * co.y;
             g[3] = dL_dG * dG_ddelx * (0.5f * (float)a.W);
@@ -200,6 +225,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             g[5] = -0.5f * gdx * dx * dL_dG;
             g[6] = -0.5f * gdx * dy * dL_dG;
             g[7] = -0.5f * gdy * dy * dL_dG;
+#endif
             g[8] = G * dL_dalpha;
             bp.T = ok ? test_T : bp.T;
             return ok;
@@ -290,7 +316,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
 #endif
 #pragma unroll
-                for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk]);
+                for (int kk = 0; kk < 9; kk++) atomicAdd(grad_slot(a, cur_id, kk), g[kk] * term_scale(kk));
             }
         }
     };
@@ -324,7 +350,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 if (STP_REPLAY_COPIES == 2) { v += (long long)s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p]; s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p] = 0ull; }
                 if (v != 0) {
                     s_acc[(term - ACC64_FIRST) * WINDOW + p] = 0ull;
-                    atomicAdd(grad_slot(a, __float_as_int(eC[pp].w), term), (float)((double)v * fx_inv));
+                    atomicAdd(grad_slot(a, __float_as_int(eC[pp].w), term), (float)((double)v * fx_inv_term));
                 }
 #endif
             }
