@@ -118,6 +118,10 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 
     BwdPixel bp;
     init_bwd_pixel(bp, a, inside, px, py);
+    // (STP_REPLAY_FOLD) channel sums of the pixel: final . dL, C . dL (running), -T_final (bg . dL)
+    const float FD = fmaf(bp.final_color[2], bp.dL_dpix[2], fmaf(bp.final_color[1], bp.dL_dpix[1], bp.final_color[0] * bp.dL_dpix[0]));
+    float CD = 0.0f;
+    const float tfbg = -bp.T_final * bp.bg_dot;
     int n = inside ? (int)a.n_contrib[(size_t)a.W * py + px] : 0;
     float md = fmaxf(fmaxf(fabsf(bp.dL_dpix[0]), fabsf(bp.dL_dpix[1])), fabsf(bp.dL_dpix[2]));
 #pragma unroll
@@ -191,6 +195,21 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             const float alpha = fminf(0.99f, co.w * G);
             const float test_T = bp.T * (1.0f - alpha);
             const bool ok = act && !(test_T < T_THRESHOLD);
+#if STP_REPLAY_FOLD
+            // dL/dalpha = sum_ch (c_ch - (final_ch - C_ch) / test_T) dL_ch  with the channel sums taken first: cd = c . dL, FD = final . dL (a
+            // constant of the pixel), CD = C . dL (a running scalar, CD += alpha T cd) -- six instructions instead of fifteen, and one
+            // accumulated scalar instead of three colours; 1 / (1 - alpha) = T / test_T costs a multiply instead of a second reciprocal
+            const float Tm = ok ? bp.T : 0.0f, tfbgm = ok ? tfbg : 0.0f;
+            const float dchannel_dcolor = alpha * Tm;
+            const float rcp_test_T = __builtin_amdgcn_rcpf(test_T);
+            const float rcp_1ma = rcp_test_T * bp.T;
+            const float cd = fmaf(cur.f.z, bp.dL_dpix[2], fmaf(cur.f.y, bp.dL_dpix[1], cur.f.x * bp.dL_dpix[0]));
+            CD = fmaf(dchannel_dcolor, cd, CD);
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) g[ch] = dchannel_dcolor * bp.dL_dpix[ch];
+            float dL_dalpha = fmaf(-rcp_test_T, FD - CD, cd) * Tm;
+            dL_dalpha = fmaf(tfbgm, rcp_1ma, dL_dalpha);
+#else
             const float Tm = ok ? bp.T : 0.0f, tfm = ok ? bp.T_final : 0.0f;
             const float dchannel_dcolor = alpha * Tm;
             const float rcp_test_T = __builtin_amdgcn_rcpf(test_T);
@@ -206,6 +225,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             }
             dL_dalpha *= Tm;
             dL_dalpha += (-tfm * rcp_1ma) * bp.bg_dot;
+#endif
             const float dL_dG = co.w * dL_dalpha;
             const float gdx = G * dx, gdy = G * dy;
 #if STP_REPLAY_FOLD
