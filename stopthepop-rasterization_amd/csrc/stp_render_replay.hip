@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     };
     // merge lanes on the same position, then add to the window's sums (lo = first position of the window)
     // deep (wave-uniform): also the two mirror levels inside the 16-lane row
-    auto merge_and_add = [&](bool ok, int cur_pos, int cur_id, float (&g)[9], int lo, const bool deep) __attribute__((always_inline)) {
+    // one_window (a literal at both call sites): the list fits the window -- no position lies in front of it, a position IS its slot
+    auto merge_and_add = [&](bool ok, int cur_pos, int cur_id, float (&g)[9], int lo, const bool deep, const bool one_window) __attribute__((always_inline)) {
 #if STP_REPLAY_PAIRMERGE
         // Pairwise merge (DPP): a lane and its partner -- lane^1, lane^2, then the mirror lanes of its 8-lane half and
         // row -- that hold the same list position sum their terms in registers and only one of them goes to LDS.  Per
@@ -329,10 +330,13 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 for (int kk = 0; kk < 9; kk++) atomicAdd(&s_accd[kk * WINDOW + (cur_pos & (WINDOW - 1))], (double)g[kk]);
             } else {
 #else
-            float gmax = fabsf(g[0]);
+            // (the three colour terms are alpha T dL/dpixel: below M each, below 16 M after the merge levels -- they cannot reach the
+            // fixed point's cap of 2^20 M and stay out of the range check)
+            float gmax = fabsf(g[3]);
 #pragma unroll
-            for (int kk = 1; kk < 9; kk++) gmax = fmaxf(gmax, fabsf(g[kk]));
-            if (cur_pos >= lo && gmax < fx_cap) { // nine adds, nothing else
+            for (int kk = 4; kk < 9; kk++) gmax = fmaxf(gmax, fabsf(g[kk]));
+            const int slot = one_window ? cur_pos : (cur_pos & (WINDOW - 1));
+            if ((one_window || cur_pos >= lo) && gmax < fx_cap) { // nine adds, nothing else
 #if STP_REPLAY_COLOR32
 #pragma unroll
                 for (int kk = 0; kk < 3; kk++) atomicAdd(&s_acc32[kk * WINDOW + (cur_pos & (WINDOW - 1))], (unsigned int)__float2int_rn(g[kk] * fx_scale32));
@@ -342,7 +346,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                     // round-to-nearest integer of g*scale through the 1.5*2^52 trick (|g*scale| < 2^51 + margin)
                     const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
                     const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
-                    atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + (cur_pos & (WINDOW - 1))], (unsigned long long)qv);
+                    atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + slot], (unsigned long long)qv);
                 }
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
 #endif
@@ -463,8 +467,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
 #endif
             const bool ok = blend_terms(have, cur, g);
-            if (have && !ok) { n = kr; pos = -1; } // (an ulp of difference against the forward's transmittance: stop where it says so)
-            merge_and_add(ok, cur_pos, cur_id, g, 0, dense);
+            if (have && !ok) n = kr; // (an ulp of difference against the forward's transmittance: stop where it says so)
+            merge_and_add(ok, cur_pos, cur_id, g, 0, dense, true);
         };
 #if STP_REPLAY_UNROLL2
         Entry en2 = en;
@@ -535,7 +539,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #endif
             const bool ok = blend_terms(act, cur, g);
             if (act && !ok) { n = k; pos = EXHAUSTED; pos1 = EXHAUSTED; } // (saturated one record earlier than the forward said)
-            merge_and_add(ok, cur_pos, cur_id, g, lo, same_start);
+            merge_and_add(ok, cur_pos, cur_id, g, lo, same_start, false);
         }
         flush_range(lo, last ? list_len : lo + STEP);
         if (last) break;
