@@ -518,7 +518,14 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
     SideStream* const side = side_stream(mb.device);
     SideJoin colours{mb.done, st, false};
-    if (side) {
+    // Where the colour kernel starts on the side stream.  Rounds 2-3: behind the mailbox, i.e. in the host's hand-over bubble and then beside
+    // duplicate_kernel -- two bandwidth-bound kernels that slow each other down (duplicate 61 us alone, 98 us beside it).  Since the host watches the
+    // mailbox word the bubble is a few microseconds, and the kernel now starts behind duplicate_kernel, beside the tile-bit sort, whose radix
+    // passes run at 1.6 TB/s and leave it room (late round 3, one box, alternating: duplicate 0.098 -> 0.058 ms, sort stage 0.289 -> 0.337, the
+    // step -6 .. -10 us at C2-full, -40 .. -70 us at C5, C3 / C4 / C2-min unchanged).  STP_COLOUR_LATE=0 restores the earlier start.
+    static const char* const late_env = std::getenv("STP_COLOUR_LATE");
+    static const bool colour_late = !(late_env && late_env[0] == '0');
+    auto colour_on_side = [&]() -> int {
         STP_TRY(hipStreamWaitEvent(side->stream, mb.ev, 0), "side stream wait");
         STP_TRY(launch_sh_color(f, g, radii, side->stream), "SH colour launch");
         // from here on the side stream works on the caller's buffers: every return path joins it (SideJoin); should the
@@ -528,6 +535,10 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
             return fail_hip(e, "record colour event");
         }
         colours.pending = true;
+        return 0;
+    };
+    if (side) {
+        if (!colour_late) { if (int rc = colour_on_side()) return rc; }
     } else STP_TRY(launch_sh_color(f, g, radii, st), "SH colour launch");
     // the binning buffer is requested BEFORE the wait, sized by the count of the previous frame of the same kind on this
     // device (+12.5 %): in the steady state of training or serving no allocator callback runs between the kernels.  The
@@ -583,6 +594,10 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     STP_TRY(launch_duplicate(f, g, radii, b, atomic_bin ? img.tile_cursor : nullptr, st), "duplicate launch");
     STP_DEBUG_SYNC("duplicate");
     g_timer.mark(2, st);
+    if (side && colour_late) {
+        STP_TRY(hipEventRecord(mb.ev, st), "record event behind duplicate");
+        if (int rc = colour_on_side()) return rc;
+    }
     if (atomic_bin) {
         STP_TRY(launch_bin_pad(b, img, R, st), "pad entries");
     } else {
