@@ -194,6 +194,11 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     _C, dev = wl._C, wl.dev
     # bring the device out of its idle power state before the contract's W warm-up steps: the first process on a fresh box
     # otherwise measures the clock ramp (seen: 299 instead of 337 frames/s); untimed, like the warm-up itself
+    # The untimed steps run WITH the stage timer switched on, like the timed ones (an event gets its signal from the runtime at its first
+    # record, not at hipEventCreate: the timer's 512 events should have been recorded once before the timed region).  The counters are reset
+    # at the start of the timed region.  (This did NOT remove the sporadic slow step -- one step of +0.5 .. +2 ms in about one default run in
+    # four on SOME boxes, none in thirty runs on others, with or without this: profiles/r03_experiments/step_outliers.txt)
+    _C.timing_enable(True)
     if wl.sharded:
         # (a tile-row step contains collectives: every rank must run the SAME number of steps -- a time-based loop would let the
         # ranks disagree and deadlock in the exchange; found by the one-GPU self-test of round 3, `--test-one-gpu`)
@@ -212,8 +217,6 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     import gc
     gc.collect()
     gc.disable()  # (a collection inside the timed region is a multi-millisecond stall of the launching thread)
-    _C.timing_enable(True)   # creates the stage timer's hipEvents (once per device) ...
-    _C.timing_enable(False)  # ... and is switched on for real right before the timed region
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     stream = torch.cuda.current_stream(dev)
     for m in marks:   # torch creates the hipEvent at the first record(): do that HERE, not inside the timed region
@@ -221,7 +224,7 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     for _ in range(warmup):
         wl.step()
     barrier()
-    _C.timing_enable(True)  # hipEvents around every stage of every timed step, on the launch stream, no extra sync
+    _C.timing_enable(True)  # (resets the stage means: hipEvents around every stage of every timed step, on the launch stream, no extra sync)
     t0 = time.perf_counter()
     marks[0].record(stream)
     cum = []
