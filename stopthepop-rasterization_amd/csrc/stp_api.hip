@@ -135,6 +135,8 @@ GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total,
     g.rgb = c.take<float>(3 * P, &off); note("rgb", off, 3 * P);
     g.tiles_touched = c.take<uint32_t>(P, &off); note("tiles_touched", off, P);
     g.point_offsets = c.take<uint32_t>(P, &off); note("point_offsets", off, P);
+    g.block_sums = c.take<uint32_t>((P + 255) / 256, &off);
+    g.block_prefix = c.take<uint32_t>((P + 255) / 256, &off);
     g.scan_temp_bytes = scan_temp_bytes(P);
     g.scan_temp = c.take<char>(g.scan_temp_bytes);
     if (total) *total = c.total();
@@ -499,12 +501,18 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     static const bool tile_local_sort = !(sort_env && std::strcmp(sort_env, "radix") == 0);
     static const bool atomic_bin = sort_env && std::strcmp(sort_env, "counters") == 0;
 
+    // STP_SCAN=rocprim: the device-wide scan of round 1-2 (rocPRIM inclusive_scan + a one-thread mailbox kernel) instead of the two-level scan
+    // folded into preprocess_kernel / duplicate_kernel (read once, like the other path switches)
+    static const char* const scan_env = std::getenv("STP_SCAN");
+    static const bool two_level_scan = !(scan_env && std::strcmp(scan_env, "rocprim") == 0);
+    if (!two_level_scan) { g.block_sums = nullptr; g.block_prefix = nullptr; }
+
     g_timer.begin_forward();
     g_timer.mark(0, st);
     STP_TRY(launch_frame_init(g, img, (int)T, with_log, atomic_bin, st), "frame init launch");
     STP_TRY(launch_preprocess(f, g, radii, atomic_bin ? img.tile_counts : nullptr, st), "preprocess launch");
     STP_DEBUG_SYNC("preprocess");
-    STP_TRY(launch_scan(f, g, st), "inclusive scan");
+    if (!two_level_scan) STP_TRY(launch_scan(f, g, st), "inclusive scan");
     STP_DEBUG_SYNC("scan");
     if (atomic_bin) STP_TRY(launch_tile_scan(f, img, st), "tile scan"); // counters -> ranges + cursors (no host value needed)
 
@@ -514,7 +522,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // the GPU keeps working while the host wakes up, sizes the buffer and launches duplicate / sort.
     Mailbox mb;
     if (int rc = acquire_mailbox(&mb)) return rc;
-    STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, mb.ticket, st), "mailbox launch");
+    if (two_level_scan) STP_TRY(launch_block_prefix_mailbox(f, g, mb.dev, mb.ticket, st), "workgroup prefixes + mailbox launch");
+    else STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, mb.ticket, st), "mailbox launch");
     STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
     SideStream* const side = side_stream(mb.device);
     SideJoin colours{mb.done, st, false};

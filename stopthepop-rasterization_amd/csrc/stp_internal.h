@@ -73,7 +73,9 @@ struct GeometryState {
     float4* conic_opacity;   // P
     float* rgb;              // 3P
     uint32_t* tiles_touched; // P
-    uint32_t* point_offsets; // P
+    uint32_t* point_offsets; // P   (inclusive scan of tiles_touched; between preprocess_kernel and duplicate_kernel: inclusive inside each block of 256)
+    uint32_t* block_sums;    // ceil(P / 256): entries of each preprocess workgroup, and their exclusive scan (two-level scan, stp_preprocess.hip)
+    uint32_t* block_prefix;  // ceil(P / 256)
     char* scan_temp;
     size_t scan_temp_bytes;
 };
@@ -162,6 +164,7 @@ hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int 
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st);
+hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st); // second level of the scan + the hand-over
 hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);

@@ -287,7 +287,10 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
             if (lane == src) { full_count = full; tile_count = mine; }
         }
     }
-    if (!alive || full_count == 0) return;
+    // (no early return: the workgroup's threads meet again for the scan at the end)
+    uint32_t my_entries = 0u;
+    if (alive && full_count != 0) {
+        my_entries = (uint32_t)tile_count;
 
     const float3 mean = o.mean, pv = o.pv;
     const float4 co = o.co;
@@ -336,6 +339,26 @@ __global__ void __launch_bounds__(256) preprocess_kernel(const PreArgs a)
         gp[1] = make_float4(s1.y, s1.z, s2.x, s2.y);
         gp[2] = make_float4(s2.z, mean2D.x, mean2D.y, 0.0f);
         gp[3] = co;
+    }
+    }
+
+    // ---- first level of the scan tiles_touched -> point_offsets (reference rasterizer_impl.cu:313, cub InclusiveSum): inclusive inside the
+    // workgroup, the workgroup's total to block_sums; block_prefix_mailbox_kernel scans the totals and duplicate_kernel adds the two levels.
+    // A device-wide scan kernel (rocPRIM: look-back state initialisation + scan, 18 us at 1 M Gaussians) is not needed for this.
+    if (a.g.block_sums != nullptr) {
+        __shared__ uint32_t s_wave_total[4];
+        const int lane = wave_lane(), wave = (int)(threadIdx.x >> 6);
+        uint32_t v = my_entries;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t)__shfl_up((int)v, d);
+            if (lane >= d) v += t;
+        }
+        if (lane == 63) s_wave_total[wave] = v;
+        __syncthreads();
+        for (int k = 0; k < wave; k++) v += s_wave_total[k];
+        if (idx < a.P) a.g.point_offsets[idx] = v;
+        if (threadIdx.x == 255) a.g.block_sums[blockIdx.x] = v;
     }
 }
 
@@ -450,9 +473,21 @@ __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
     DupGaussian g{};
     float3 cam = make_float3(0, 0, 0);
     if (per_tile_depth) cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
-    if (valid) {
+    if (a.g.block_prefix != nullptr) {
+        // second half of the two-level scan: workgroup prefix + the inclusive value inside the workgroup (preprocess_kernel, same 256 Gaussians);
+        // the global inclusive scan is left in point_offsets (what the reference's buffer holds) once every thread has read its neighbour's value
+        if (idx < a.P) {
+            const uint32_t base = a.g.block_prefix[blockIdx.x];
+            off = base + (threadIdx.x == 0 ? 0u : a.g.point_offsets[idx - 1]);
+            off_to = base + a.g.point_offsets[idx];
+        }
+        __syncthreads();
+        if (idx < a.P) a.g.point_offsets[idx] = off_to;
+    } else if (valid) {
         off = (idx == 0) ? 0u : a.g.point_offsets[idx - 1];
         off_to = a.g.point_offsets[idx];
+    }
+    if (valid) {
         g.xy = a.g.means2D[idx];
         const float2 ext = a.g.rects2D[idx];
         get_rect(g.xy, ext, a.gx, a.gy, a.ty0, a.ty1, x0, y0, x1, y1);
@@ -604,6 +639,42 @@ __global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const u
     __threadfence_system();
     mailbox[2] = ticket; // the host may be watching this word (stp_forward): it goes out after the two values
     __threadfence_system();
+}
+
+// Second level of the scan + the hand-over, one workgroup: exclusive scan of the preprocess workgroups' totals (thread t takes a run of
+// consecutive totals), num_rendered = the grand total and the status word into host-mapped memory, the ticket last (see mailbox_kernel).
+__global__ void __launch_bounds__(1024) block_prefix_mailbox_kernel(const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_prefix, int n_blocks,
+                                                                     const uint32_t* __restrict__ status, volatile uint32_t* mailbox, uint32_t ticket)
+{
+    __shared__ uint32_t s_wave_total[16];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n_blocks + 1023) / 1024, i0 = min(tid * per, n_blocks), i1 = min(i0 + per, n_blocks);
+    uint32_t mine = 0u;
+    for (int i = i0; i < i1; i++) mine += block_sums[i];
+    uint32_t v = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)v, d);
+        if (lane >= d) v += t;
+    }
+    if (lane == 63) s_wave_total[wave] = v;
+    __syncthreads();
+    for (int k = 0; k < wave; k++) v += s_wave_total[k];
+    uint32_t run = v - mine; // exclusive prefix of this thread's run
+    for (int i = i0; i < i1; i++) { block_prefix[i] = run; run += block_sums[i]; }
+    if (tid == 1023) {
+        mailbox[0] = v;
+        mailbox[1] = status[1];
+        __threadfence_system();
+        mailbox[2] = ticket;
+        __threadfence_system();
+    }
+}
+
+hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st)
+{
+    hipLaunchKernelGGL(block_prefix_mailbox_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_prefix, (f.P + 255) / 256, g.status, mailbox_dev, ticket);
+    return hipGetLastError();
 }
 
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st)
