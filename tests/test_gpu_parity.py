@@ -507,6 +507,29 @@ def test_reference_style_full_radix_sort_still_selectable(monkeypatch, scene_kw)
             assert np.array_equal(outs["radix"][part], outs[mode][part]), (mode, part)
 
 
+def test_scan_and_colour_stream_switches_change_nothing():
+    """STP_SCAN=rocprim (device-wide scan of the tile counts instead of the two-level scan inside preprocess / duplicate) and
+    STP_COLOUR_LATE=0 (the colour kernel beside duplicate_kernel instead of behind it) are schedules, not results: point_offsets,
+    the unsorted and sorted keys, the sorted list and the frame are the default's bit for bit.  (Read once per process: children.)"""
+    import os, subprocess, sys, tempfile
+    code = ("import sys, numpy as np; sys.path[:0] = ['tests', 'stopthepop-rasterization_amd', '.']; import conftest;"
+            "from helpers import *; from diff_gaussian_rasterization import scenes;"
+            "sc = scenes.make_scene(P=5000, W=200, H=120, sigma_min=1.0, sigma_max=30.0, seed=23, camera='orbit');"
+            "g = GpuRun(sc, settings_dict(3, order=3, rect=True, tight=True, tbc=True, h44=True, lb=True));"
+            "np.savez(sys.argv[1], color=g.color, offsets=g.geom_array('point_offsets'), ku=g.binning_array('keys_unsorted'),"
+            " k=g.binning_array('keys'), l=g.binning_array('point_list'), n=np.int64(g.num_rendered))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for name, extra in (("default", {}), ("rocprim", {"STP_SCAN": "rocprim"}), ("early", {"STP_COLOUR_LATE": "0"})):
+            f = os.path.join(d, name + ".npz")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, **extra), cwd=root)
+            outs[name] = dict(np.load(f))
+    for name in ("rocprim", "early"):
+        for part in ("n", "offsets", "ku", "k", "l", "color"):
+            assert np.array_equal(outs["default"][part], outs[name][part]), (name, part)
+
+
 def test_second_backward_after_buffer_recycling_fails_loudly():
     """retain_graph + a later forward that reuses the pooled scratch buffers: the second backward must raise instead
     of replaying somebody else's tile lists."""
