@@ -341,10 +341,121 @@ def hbm_ceilings(dev):
     return out
 
 
+FMA_LIB_NAME = "libstp_raster_fma.so"
+GRAD_NAMES = ("dL_dmeans3D", "dL_dmeans2D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh")
+
+
+def product_frame(wl):
+    """One untimed step of `wl` with the library currently loaded + one direct _C forward: what the whole-frame parity records
+    compare -- image, gradients, num_rendered, the 64-bit sort keys and the sorted Gaussian list (host copies)."""
+    _C, rs = wl._C, wl.rs
+    for x in wl.leaves:
+        if x is not None:
+            x.grad = None
+    wl.step()
+    color = wl.state["color"].detach().cpu().numpy()
+    grads = None
+    if not wl.fwd_only:
+        grads = {n: (None if x.grad is None else x.grad.detach().cpu().numpy())
+                 for n, x in zip(GRAD_NAMES, (wl.means3D, wl.means2D, wl.opac, wl.scales, wl.rots, wl.shs))}
+    empty = torch.Tensor([])
+    o1 = _C.rasterize_gaussians(rs.bg, wl.means3D.detach(), empty, wl.opac.detach(), wl.scales.detach(), wl.rots.detach(), 1.0, empty,
+                                rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
+                                rs.image_width, wl.shs.detach(), rs.sh_degree, rs.campos, False, dict(wl.sdict), False, False)
+    R = int(o1[0])
+    keys = _C.binning_array(o1[4], R, "keys").cpu().numpy().view(np.uint64) if R else np.zeros(0, np.uint64)
+    plist = _C.binning_array(o1[4], R, "point_list").cpu().numpy().view(np.uint32) if R else np.zeros(0, np.uint32)
+    _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
+    del o1
+    return {"color": color, "grads": grads, "num_rendered": R, "keys": keys, "point_list": plist}
+
+
+class ReferenceFrame:
+    """THE REFERENCE'S OWN KERNELS (oracle/_ref: hipify-perl + hipcc build, test infrastructure) on the whole frame of a
+    workload: image, gradients, keys, list -- run once per workload, compared with as many product builds as wanted."""
+
+    def __init__(self, scene, sdict, fwd_only, variant="ieee"):
+        from oracle import reference as ref
+        self.note = None
+        rf = ref.forward_scene(scene, sdict, variant=variant)
+        self.build = ref.build_info(variant)
+        self.num_rendered = int(rf.num_rendered)
+        self.color = rf.color
+        self.keys = rf.array("keys").view(np.uint64) if self.num_rendered else np.zeros(0, np.uint64)
+        self.point_list = rf.array("point_list").view(np.uint32) if self.num_rendered else np.zeros(0, np.uint32)
+        self.grads = None if fwd_only else rf.backward(scene.dL_dout)
+        self.rf = rf
+
+    def compare(self, prod):
+        rec = {"build": self.build, "frame": "whole frame", "num_rendered_equal": bool(prod["num_rendered"] == self.num_rendered)}
+        if rec["num_rendered_equal"]:
+            kd = int((prod["keys"] != self.keys).sum())
+            ld = int((prod["point_list"] != self.point_list).sum())
+            rec.update({"keys_bit_equal": kd == 0, "keys_differing": kd, "list_bit_equal": ld == 0, "list_entries_differing": ld,
+                        "list_entries": int(self.keys.size)})
+        rec.update(_img_err(prod["color"], self.color))
+        if prod["grads"] is not None and self.grads is not None:
+            rec.update(_grad_err(prod["grads"], self.grads))
+        if self.note:
+            rec["note"] = self.note
+        return rec
+
+    def free(self):
+        if self.rf is not None:
+            self.rf.free()
+            self.rf = None
+
+
+def reference_parity(wl, dev, timing_steps=10, timing_warmup=3, with_fma=True, time_fma=True):
+    """Whole-frame parity of one workload against the reference's IEEE build, for the default library and for the second shipped
+    library (libstp_raster_fma.so), and the latter's speed in the same harness.  Returns {} when oracle/_ref is absent."""
+    from oracle import reference as ref
+    from diff_gaussian_rasterization import _C
+    if not ref.available("ieee"):
+        return {}
+    out = {}
+    rfr = ReferenceFrame(wl.scene, wl.sdict, wl.fwd_only)
+    try:
+        prod = product_frame(wl)
+        first = rfr.compare(prod)
+        if not first.get("keys_bit_equal", False) and wl.sdict.get("load_balancing") and wl.sdict["culling_settings"]["tile_based_culling"]:
+            # load_balancing + tile_based_culling: the reference computes its write offsets with `0xFFFFFFFFU >> (32 - lane)`
+            # (stopthepop_common.cuh:519-520), a shift by 32 for lane 0 -- undefined; NVIDIA hardware clamps it to 0, gfx950 wraps it to a shift
+            # by 0, so THIS build of the reference emits a different list wherever a Gaussian takes that path (more than 32 tiles).  On CUDA
+            # the flag changes no result (SURVEY.md section 0): the reference is re-run without it and both records are kept.
+            rfr.free()
+            rfr = ReferenceFrame(wl.scene, {**wl.sdict, "load_balancing": False}, wl.fwd_only)
+            rfr.note = ("reference run with load_balancing=false: with it, stopthepop_common.cuh:519-520 shifts by 32 (undefined; this build of the "
+                        "reference then emits another list, see as_configured); the flag changes no result on CUDA")
+            out["vs_reference_ieee_build"] = rfr.compare(prod)
+            out["vs_reference_ieee_build"]["as_configured"] = {k: first[k] for k in first if k != "build"}
+        else:
+            out["vs_reference_ieee_build"] = first
+        fma = os.path.join(os.path.dirname(_C.library_path()), FMA_LIB_NAME)
+        if with_fma and os.path.exists(fma) and os.path.basename(_C.library_path()) != FMA_LIB_NAME:
+            _C.use_library(fma)
+            wl._C = _C
+            try:
+                rec = {"library": FMA_LIB_NAME, "what": "the second shipped build: depthAlongRay as fused multiply-add chains (the default of rounds 1-3)"}
+                rec["vs_reference_ieee_build"] = rfr.compare(product_frame(wl))
+                if time_fma:
+                    dt, stage_ms, stats, _ = timed_region(wl, timing_steps, timing_warmup, 0.0, lambda: torch.cuda.synchronize(dev))
+                    rec.update({"value": round(timing_steps / dt, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * dt / timing_steps, 4),
+                                "steps": timing_steps, "step_ms": {k: stats[k] for k in ("median", "min", "max")} if stats else {},
+                                "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}})
+                out["fma_depth_build"] = rec
+            finally:
+                _C.use_library(None)
+                _C.clear_scratch_pool(dev)
+    finally:
+        rfr.free()
+    return out
+
+
 OTHER_WORKLOADS = (("C2-min", "C2", "min", False), ("C3", "C3", "full", False), ("C4-1gpu-fwd", "C4", "full", True), ("C5", "C5", "full", False))
 
 
-def other_workloads(dev, steps=10, warmup=3):
+def other_workloads(dev, steps=10, warmup=3, parity=True):
     """The BASELINE configurations that are not the headline, `steps` timed steps each on the same code in the same process
     (same harness as the headline: wall clock between two synchronisations, stage hipEvents, SURVEY 8(d) bytes)."""
     out = {}
@@ -362,6 +473,11 @@ def other_workloads(dev, steps=10, warmup=3):
                           "dominant_kernel": roof["kernel"], "dominant_ms": roof["avg_launch_ms"],
                           "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "achieved_GBps": roof["achieved"],
                           "frac": roof["frac"]}
+            if parity:
+                try:   # whole frame against the reference's own kernels (IEEE build), default library and libstp_raster_fma.so (+ its speed)
+                    out[label].update(reference_parity(wl, dev, timing_steps=steps, timing_warmup=warmup, time_fma=label in ("C3", "C5")))
+                except Exception as ex:
+                    out[label]["vs_reference_error"] = repr(ex)[:300]
             wl.free()
             del wl
         except Exception as ex:  # the headline stands on its own
@@ -590,7 +706,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             checker = checker_legs(scene, sdict, gy, fwd_only, args.cpu_rows, wl.state, wl.leaves,
                                    raster_factory=lambda e: __import__("diff_gaussian_rasterization").GaussianRasterizer(wl.rs._replace(settings=e)),
-                                   es=es, tensors=wl.tensors(), w_img=wl.w_img)
+                                   es=es, tensors=wl.tensors(), w_img=wl.w_img, wl=wl, dev=dev)
             out.update(checker)
         if world == 1 and not args.no_other_workloads and args.workload == "C2" and args.variant == "full" and args.scale == 1.0 \
                 and not args.fwd_only and not args.train_forward_only:
@@ -651,7 +767,7 @@ def _img_err(a, b):
     return {"psnr_db": _psnr(a, b), "max_abs": float(d.max()), "pixels_moved_gt_2e-6": int((d > 2e-6).any(axis=0).sum()), "pixels": int(d[0].size)}
 
 
-def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory, es, tensors, w_img):
+def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory, es, tensors, w_img, wl=None, dev=None):
     """The checker / baseline leg (rank 0, N = 1): everything here is test infrastructure from oracle/, used as the thing
     compared AGAINST and as reported non-target baselines, never as the thing measured.
       cpu_baseline            the CPU oracle timed on a bounded window of the same frame
@@ -678,7 +794,9 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
     img_o = ofr.color[:, sl]
     par = {"against": "CPU oracle; the oracle is held bit-for-bit in all integer / state results to the reference's own sources built for gfx950 by "
                       "hipify-perl + a 40-line adapter header + hipcc -ffp-contract=off (tests/test_reference_golden.py) -- NOT an nvcc build: by the "
-                      "tier rules that pin counts as 'parity unpinned / partial'",
+                      "tier rules that pin counts as 'parity unpinned / partial'.  vs_reference_*: the same build of the reference run on the whole "
+                      "timed frame on this GPU; the default library evaluates depthAlongRay uncontracted like that build (keys / lists bit-equal), "
+                      "fma_depth_build is the second shipped library",
            "window": f"tile rows {y0}..{y0 + nrows - 1} of {gy} of the timed frame",
            **_img_err(img_p, img_o)}
     if not fwd_only:
@@ -686,43 +804,43 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
         par.update(_grad_err(grab(), ograds))
     ofr.free()
     out["parity"] = par
-    # the reference itself on this GPU: whole frame, both builds when present
+    # the reference itself on this GPU: whole frame, both builds when present; the default library and the second shipped one
     try:
         from oracle import reference as ref
-        full_img = state["color"].detach().cpu().numpy()
-        for x in leaves:
-            if x is not None:
-                x.grad = None
-        if not fwd_only:
-            c_full, _ = raster_factory(es)(means3D, means2D, opac, shs=shs, scales=scales, rotations=rots)
-            (c_full * w_img).sum().backward()
-            full_img = c_full.detach().cpu().numpy()
-            pg = grab()
+        from diff_gaussian_rasterization import _C
+        prod = product_frame(wl)
         for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
             if not ref.available(variant):
                 continue
-            rf = ref.forward_scene(scene, sdict, variant=variant)
-            rec = {"build": ref.build_info(variant), "frame": "whole timed frame", "num_rendered_equal": bool(rf.num_rendered == int(out_num_rendered(state, rf))),
-                   **_img_err(full_img, rf.color)}
-            if not fwd_only:
-                rg = rf.backward(scene.dL_dout)
-                rec.update(_grad_err(pg, rg))
+            rfr = ReferenceFrame(scene, sdict, fwd_only, variant=variant)
+            par[key] = rfr.compare(prod)
+            if variant == "ieee":
+                fma = os.path.join(os.path.dirname(_C.library_path()), FMA_LIB_NAME)
+                if os.path.exists(fma) and os.path.basename(_C.library_path()) != FMA_LIB_NAME:
+                    # the second shipped build (depth keys as fma chains, the default of rounds 1-3): same frame, same harness
+                    _C.use_library(fma)
+                    try:
+                        rec = {"library": FMA_LIB_NAME, "what": "the second shipped build: depthAlongRay as fused multiply-add chains (the default of rounds 1-3); "
+                               "select with STP_RASTER_LIB=fma"}
+                        rec["vs_reference_ieee_build"] = rfr.compare(product_frame(wl))
+                        k2 = 20
+                        dt2, stage2, stats2, _ = timed_region(wl, k2, 5, 0.0, lambda: torch.cuda.synchronize(dev))
+                        rec.update({"value": round(k2 / dt2, 3), "unit": "frames/s", "ms_per_step": round(1000.0 * dt2 / k2, 4), "steps": k2,
+                                    "step_ms": {k: stats2[k] for k in ("median", "min", "max")} if stats2 else {},
+                                    "stage_ms": {k: round(v, 4) for k, v in stage2.items()}})
+                        out["fma_depth_build"] = rec
+                    finally:
+                        _C.use_library(None)
             if variant == "fast":
-                f_ms, b_ms = rf.time_steps(None if fwd_only else scene.dL_dout, warmup=1, steps=3)
+                f_ms, b_ms = rfr.rf.time_steps(None if fwd_only else scene.dL_dout, warmup=1, steps=3)
                 out["reference_on_this_gpu"] = {
                     "value": round(1000.0 / (f_ms + b_ms), 3), "unit": "frames/s", "fwd_ms": round(f_ms, 2), "bwd_ms": round(b_ms, 2),
                     "kind": "the reference's own kernels, hipify-perl + hipcc defaults for gfx950 (oracle/_ref; CUDA-tuned code on wave64, "
                             "NOT a statement about NVIDIA hardware; nothing is published, so vs_baseline stays null)", "steps": 3}
-            rf.free()
-            par[key] = rec
+            rfr.free()
     except Exception as ex:  # the headline stands on its own
         par["vs_reference_error"] = repr(ex)[:300]
     return out
-
-
-def out_num_rendered(state, rf):
-    fn = state["color"].grad_fn
-    return getattr(fn, "num_rendered", rf.num_rendered) if fn is not None else rf.num_rendered
 
 
 def cpu_baseline(scene, sdict, gy, fwd_only, rows):

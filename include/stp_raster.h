@@ -163,10 +163,10 @@ int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Sizes of the three scratch buffers (the reference's `required<State>()`, rasterizer_impl.h:68-75). */
 size_t stp_geometry_buffer_size(int P, const StpSettings* settings);
 size_t stp_binning_buffer_size(int R);
-size_t stp_image_buffer_size(int width, int height);
+size_t stp_image_buffer_size(int width, int height); /* without the optional blend log */
 /* Bytes the blend log adds to the image buffer of a forward with StpSettings.record_blend_log = 1 in the hierarchical / k-buffer modes
    (514 B per pixel of the 16x16 tile grid): what a caller that holds several un-backpropagated forwards has to budget for. */
-size_t stp_blend_log_bytes(int width, int height); /* without the optional blend log (+ 512 B per tile pixel) */
+size_t stp_blend_log_bytes(int width, int height);
 
 /* Introspection of the (otherwise opaque) scratch buffers, for parity tests and debugging.
    Fills byte offset and element count of a named sub-array; returns 0 or STP_ERR_INVALID_ARGUMENT.

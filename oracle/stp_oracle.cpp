@@ -208,16 +208,18 @@ inline M3 compute_cov2D_full(V3 t, float fx, float fy, float tan_fovx, float tan
 }
 
 // ref: stopthepop_common.cuh:44-55.  pack = 3 x float4: [S00 S01 S02 .][S11 S12 S22 .][u0 u1 u2 .]
-// Canonical evaluation order (shared with the HIP kernels so that depth keys compare bit-for-bit):
-// every dot product is fma(c, z, fma(b, y, a*x)) with correctly rounded fused multiply-adds, the
-// reciprocal is the IEEE quotient 1/x.  (The CUDA reference lets nvcc contract these sums as it likes.)
+// Two evaluation orders, both shared with the HIP kernels so that depth keys compare bit-for-bit: the reference's
+// expression with every product and sum rounded on its own (the default, g_ieee_depth = 1), and the fma chains of
+// libstp_raster_fma.so (every dot product fma(c, z, fma(b, y, a*x))); the reciprocal is the IEEE quotient 1/x in
+// both.  (The CUDA reference lets nvcc contract these sums as it likes.)
 int g_lazy_pop = 0;   // test-only switch "lazy_pop": a candidate that FAILS its tests is not shown to the pixel at all (no
                       // pop-before-look for it) -- the claim the wave64 kernels rest on (stp_render_hier.inc filter_push,
                       // stp_render_kbuf.hip) is that this changes no image, no final_T and no gradient; tests/test_oracle_cpu.py
                       // holds the oracle to it bit for bit.  (n_contrib of the k-buffer counts looked-at entries and does change.)
-int g_ieee_depth = 0; // test-only switch "ieee_depth": the reference's expression with NO contraction (every product and
+int g_ieee_depth = 1; // switch "ieee_depth", default 1: the reference's expression with NO contraction (every product and
                       // sum rounded separately, in the order stopthepop_common.cuh:47-51 writes them) -- what the
-                      // -ffp-contract=off build of the reference itself (oracle/_ref/libstp_ref_ieee.so) computes.
+                      // -ffp-contract=off build of the reference itself (oracle/_ref/libstp_ref_ieee.so) computes, and what
+                      // the default product library computes since round 4.  0: the fma order of libstp_raster_fma.so.
 inline float depth_along_ray(const float* pk, V3 v)
 {
     if (g_ieee_depth) {

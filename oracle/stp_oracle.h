@@ -92,8 +92,9 @@ int orc_cull_alpha(const OrcFrame* frame, int tile, int cx, int cy, double* out,
 
 /* Test-only switches.  "ewa_exact_grad"=1: use the mathematically exact Mip-Splatting scaling
    gradient instead of the reference's (see stp_oracle.cpp backward_preprocess).
-   "ieee_depth"=1: evaluate depthAlongRay without fused multiply-adds, as the -ffp-contract=off build of the
-   reference itself does (oracle/_ref/libstp_ref_ieee.so); default 0 = the fma order shared with the HIP kernels.
+   "ieee_depth": 1 (default) = evaluate depthAlongRay without fused multiply-adds, as the -ffp-contract=off build of the
+   reference itself (oracle/_ref/libstp_ref_ieee.so) and the default product library do; 0 = the fma order of the
+   second product library, libstp_raster_fma.so.
    "lazy_pop"=1: in the hierarchical head level and the k-buffer, a candidate that fails its tests causes no
    pop-before-look -- images, final_T and gradients must not change (tests/test_oracle_cpu.py); default 0 = the reference. */
 void orc_set_flag(const char* name, int value);

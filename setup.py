@@ -2,7 +2,8 @@
 
     pip install --no-build-isolation -e .        # or: pip install --no-build-isolation .
 
-builds libstp_raster.so with hipcc for gfx950 (make -C stopthepop-rasterization_amd/csrc) and the native torch binding
+builds libstp_raster.so (and the second library, libstp_raster_fma.so: INTEGRATION.md section 5) with hipcc for gfx950
+(make -C stopthepop-rasterization_amd/csrc [FMA_DEPTH=1]) and the native torch binding
 _stp_host with g++ (csrc/host/build_host.py: host code only -- no kernel goes through a torch extension, hence no hipify
 pass) and installs the package `diff_gaussian_rasterization` with both as package data.
 The repository's test-side directories (oracle/, tests/, tools/) are not installed."""
@@ -21,17 +22,18 @@ class BuildWithLibrary(build_py):
     def run(self):
         jobs = str(min(8, os.cpu_count() or 1))
         subprocess.check_call(["make", "-C", os.path.join(ROOT, PKG_PARENT, "csrc"), "-j", jobs, "ARCH=gfx950"])
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, PKG_PARENT, "csrc"), "-j", jobs, "ARCH=gfx950", "FMA_DEPTH=1"])
         subprocess.check_call([sys.executable, os.path.join(ROOT, PKG_PARENT, "csrc", "host", "build_host.py")])
         super().run()
 
 
 setup(
     name="diff_gaussian_rasterization",
-    version="0.3.0",
+    version="0.4.0",
     description="MI355X-native sorted Gaussian-splat rasterizer behind the StopThePop diff_gaussian_rasterization API",
     packages=["diff_gaussian_rasterization"],
     package_dir={"": PKG_PARENT},
-    package_data={"diff_gaussian_rasterization": ["libstp_raster.so", "_stp_host*.so"]},
+    package_data={"diff_gaussian_rasterization": ["libstp_raster.so", "libstp_raster_fma.so", "_stp_host*.so"]},
     cmdclass={"build_py": BuildWithLibrary},
     python_requires=">=3.9",
     install_requires=[],   # torch (ROCm build) is expected in the environment, as with the reference

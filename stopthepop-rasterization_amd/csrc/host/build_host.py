@@ -4,13 +4,12 @@
 A torch CppExtension in everything but the driver: ONE g++ command with torch's own include / library paths and ABI flag
 (torch.utils.cpp_extension reports them), no .hip / .cu source and therefore no hipify pass; the result lands IN-TREE next
 to _C.py so that it travels with the repository snapshot (a JIT cache under ~/.cache would not).  Host code only: it
-compiles on a box without a GPU.   usage: python build_host.py [-v]"""
+compiles on a box without a GPU.  pybind11 comes from torch's own bundled headers (ce.include_paths()).   usage: python build_host.py [-v]"""
 import os
 import subprocess
 import sys
 import sysconfig
 
-import pybind11
 import torch
 from torch.utils import cpp_extension as ce
 
@@ -23,7 +22,7 @@ OUT = os.path.join(PKG, NAME + sysconfig.get_config_var("EXT_SUFFIX"))
 
 def command():
     torch_lib = os.path.join(os.path.dirname(torch.__file__), "lib")
-    inc = ce.include_paths() + [pybind11.get_include(), sysconfig.get_paths()["include"], "/opt/rocm/include"]
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], "/opt/rocm/include"]
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
            "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", f"-DTORCH_EXTENSION_NAME={NAME}", "-DTORCH_API_INCLUDE_EXTENSION_H",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}"]

@@ -20,6 +20,7 @@
 // its buffers were recycled (check_scratch).
 #include <torch/extension.h>
 
+#include <c10/hip/HIPCachingAllocator.h>
 #include <c10/hip/HIPGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <hip/hip_runtime_api.h>
@@ -89,11 +90,20 @@ void need_library()
     throw std::runtime_error((msg && *msg) ? std::string(msg) : "libstp_raster error " + std::to_string(rc));
 }
 
+// A pooled buffer is used on whichever stream is current when it is handed out, not only on the stream torch::empty allocated it on: the caching
+// allocator must know, or it could re-issue the block -- once the pool evicts it -- while kernels of another stream still read it.  (A no-op for
+// the allocation stream itself, i.e. for single-stream training.)
+void note_stream_use(const torch::Tensor& buf)
+{
+    c10::hip::HIPCachingAllocator::recordStream(buf.storage().data_ptr(), c10::hip::getCurrentHIPStream(buf.get_device()));
+}
+
 void put_back(const torch::Tensor& buf) // caller holds g_mutex
 {
     auto& fl = g_free[buf.get_device()];
     for (auto& p : fl)
         if (p.t.data_ptr() == buf.data_ptr()) return;
+    note_stream_use(buf);
     hipEvent_t& ev = g_events[(uintptr_t)buf.data_ptr()];
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
     bool recorded = ev && hipEventRecord(ev, c10::hip::getCurrentHIPStream(buf.get_device()).stream()) == hipSuccess;
@@ -131,6 +141,7 @@ struct Resizer {
                     if (p.ev) // the releasing stream's kernels may still be reading it: order this stream behind them
                         (void)hipStreamWaitEvent(c10::hip::getCurrentHIPStream(p.t.get_device()).stream(), p.ev, 0);
                     self->t = p.t;
+                    note_stream_use(self->t);
                 } else self->t = torch::empty({cap}, self->t.options());
                 self->from_pool = true;
                 g_generation[(uintptr_t)self->t.data_ptr()]++;

@@ -302,6 +302,17 @@ struct SideJoin { // joins the side stream's work into `st` when it goes out of 
     ~SideJoin() { (void)join(); }
 };
 
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
+
 int acquire_mailbox(Mailbox* out)
 {
     int device = 0;
@@ -316,6 +327,7 @@ int acquire_mailbox(Mailbox* out)
                     hipEventCreateWithFlags(&ring.slot[i].ev, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&ring.slot[i].done, hipEventDisableTiming) != hipSuccess)
                     return fail(STP_ERR_HIP, "cannot create the num_rendered mailbox");
+                std::memset(h, 0, 64); // (a recycled pinned page may hold an old ticket: the first tickets are the small integers 1..8)
                 ring.slot[i].host = static_cast<volatile uint32_t*>(h);
                 ring.slot[i].dev = static_cast<uint32_t*>(d);
                 ring.slot[i].device = device;
@@ -579,7 +591,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
                 if (q != hipErrorNotReady) return fail_hip(q, "query (num_rendered)");
                 if (it > (1u << 22)) { STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)"); break; } // (seconds of spinning: stop burning a core)
             }
-            __builtin_ia32_pause();
+            cpu_relax();
         }
         std::atomic_thread_fence(std::memory_order_acquire);
     } else STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");

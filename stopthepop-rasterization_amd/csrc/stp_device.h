@@ -210,13 +210,14 @@ __device__ __forceinline__ float exp_blend(float x)
 }
 
 // Depth of the point of maximum contribution along a view ray (reference stopthepop_common.cuh:44-55).
-// p0 = [S00 S01 S02], p1 = [S11 S12 S22], p2 = Sigma^-1 (mu - cam).  Canonical evaluation order:
-// every dot product is fma(c, z, fma(b, y, a*x)); the reciprocal is the IEEE quotient 1/x.
+// p0 = [S00 S01 S02], p1 = [S11 S12 S22], p2 = Sigma^-1 (mu - cam).  The reciprocal is the IEEE quotient 1/x in both forms.
 #ifndef STP_IEEE_DEPTH
-#define STP_IEEE_DEPTH 0 // 1 (`make IEEE_DEPTH=1`, a TEST-ONLY second library, never the default): the reference's expression with NO
-                         // contraction, every product and sum rounded on its own in the order stopthepop_common.cuh:47-51 writes
-                         // them -- what the -ffp-contract=off build of the reference computes.  With it the product's sort keys,
-                         // tile lists and per-pixel orders are the reference's bit for bit (tests/test_reference_pin.py).
+#define STP_IEEE_DEPTH 1 // 1 (the default since round 4): the reference's expression with NO contraction, every product and sum rounded
+                         // on its own in the order stopthepop_common.cuh:47-51 writes them -- what the -ffp-contract=off build of the
+                         // reference computes.  With it the sort keys, tile lists and per-pixel orders are the reference's bit for bit
+                         // (tests/test_reference_pin.py).  0 (`make FMA_DEPTH=1` -> libstp_raster_fma.so): every dot product is
+                         // fma(c, z, fma(b, y, a*x)), ten VALU instructions fewer per evaluation (forward render -3.7 % at C2-full);
+                         // keys then sit an ulp off the reference's now and then and list neighbours swap.
 #endif
 template <bool FAST = false> __device__ __forceinline__ float depth_along_ray(float3 p0, float3 p1, float3 p2, float3 v)
 {

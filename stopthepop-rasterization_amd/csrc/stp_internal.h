@@ -91,7 +91,7 @@ struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges 
     uint32_t* tile_cursor; // T
     uint32_t* bin_total;   // 2
     uint32_t* tile_flags; // T   0 = this tile's log is valid, 1 = its log overflowed, 0xFFFFFFFF = the forward recorded no log
-    uint32_t* blend_log;  // T * 4 waves * BLEND_LOG_DEPTH * 64 lanes (only with the blend log)
+    uint32_t* blend_log;  // T * 4 waves * BLEND_LOG_ROWS * 64 lanes of u16 (only with the blend log)
 };
 
 struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217

@@ -58,12 +58,6 @@ namespace {
                              // six geometric ones stay 64-bit.  MEASURED (round 3, one box, alternating): C2-full 0.947 against 0.928 ms,
                              // C2-min 1.056 against 1.008, C3 1.87 against 1.72 -- no faster anywhere; kept as a switch for the record.
 #endif
-#if STP_REPLAY_FOLD && (STP_REPLAY_F64 || STP_REPLAY_COLOR32 || !STP_REPLAY_STRAIGHT)
-#error "STP_REPLAY_FOLD is written for the 64-bit fixed-point sums of the straight-line step"
-#endif
-#if STP_REPLAY_COLOR32 && STP_REPLAY_F64
-#error "STP_REPLAY_F64 keeps all nine sums as doubles"
-#endif
 #ifndef STP_REPLAY_WINDOW
 #define STP_REPLAY_WINDOW 512
 #endif
@@ -75,6 +69,13 @@ namespace {
 #endif
 #ifndef STP_REPLAY_STRAIGHT
 #define STP_REPLAY_STRAIGHT 1 // the gradient terms of a step as straight-line code (see blend_terms); 0: the branchy form of rounds 1-3
+#endif
+// (checked BELOW the defaults: a -DSTP_REPLAY_F64=1 build must say -DSTP_REPLAY_FOLD=0 too -- its flush writes the sums without the folded factors)
+#if STP_REPLAY_FOLD && (STP_REPLAY_F64 || STP_REPLAY_COLOR32 || !STP_REPLAY_STRAIGHT)
+#error "STP_REPLAY_FOLD is written for the 64-bit fixed-point sums of the straight-line step"
+#endif
+#if STP_REPLAY_COLOR32 && STP_REPLAY_F64
+#error "STP_REPLAY_F64 keeps all nine sums as doubles"
 #endif
 constexpr int WINDOW = STP_REPLAY_WINDOW; // list positions per window (9 x 512 x 8 B = 36 KB of LDS: four workgroups per CU)
 constexpr int EXHAUSTED = 0x7fffffff; // "position" of a lane that has no record left

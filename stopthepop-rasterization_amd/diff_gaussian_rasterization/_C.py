@@ -41,13 +41,17 @@ _lib_override = None
 
 
 def library_path() -> str:
-    return _lib_override or os.environ.get("STP_RASTER_LIB", os.path.join(_HERE, _LIB_NAME))
+    p = _lib_override or os.environ.get("STP_RASTER_LIB", os.path.join(_HERE, _LIB_NAME))
+    return os.path.join(_HERE, "libstp_raster_fma.so") if p == "fma" else p   # (STP_RASTER_LIB=fma: the shipped second build, by name)
 
 
 def use_library(path=None) -> None:
-    """Test hook: the next call loads `path` instead of the product library (None: back to the default).  Used to run the
-    test-only IEEE-depth build (`make IEEE_DEPTH=1`, libstp_raster_ieee.so) against the reference's fixtures."""
+    """The next call loads `path` instead of the default library (None: back to the default).  `path` may be a file or one of the
+    shipped builds by name: "fma" = libstp_raster_fma.so (depth keys as fused multiply-add chains: 1.4-3 % faster, keys an ulp off the
+    reference's now and then), "default" = libstp_raster.so (the reference's uncontracted depth keys)."""
     global _lib, _host, _lib_override
+    if path in ("fma", "default"):
+        path = os.path.join(_HERE, "libstp_raster_fma.so" if path == "fma" else _LIB_NAME)
     _lib, _host, _lib_override = None, None, path
 
 

@@ -8,9 +8,10 @@ faithful CPU restatement has to reproduce, BIT FOR BIT:
     sorted Gaussian list, the tile ranges, n_contrib, markVisible,
 in every sort mode / order / culling / queue-size combination the fixtures hold.  Two documented exceptions:
   * rects2D under tight_opacity_bounding: <= 2 ulp (one logf: the device library's vs the oracle's rounded double log);
-  * depthAlongRay: the oracle's default evaluation uses fused multiply-adds in the order the HIP kernels share
-    (the CUDA reference leaves contraction to nvcc); the test switch "ieee_depth" selects the uncontracted form, which
-    is what this build of the reference computes.  Both are checked: ieee_depth=1 exactly, the default at tolerance.
+  * depthAlongRay: the oracle's default evaluation (like the default product library's since round 4) is the reference's
+    uncontracted expression, which is what this build of the reference computes: checked exactly.  The switch
+    "ieee_depth"=0 selects the fused multiply-add order of the second product library (libstp_raster_fma.so; the CUDA
+    reference leaves contraction to nvcc): checked at tolerance.
 Blend results (libm expf on one side, the device's on the other): image <= 2e-6, gradients <= 2e-5 of the largest entry.
 """
 import glob
@@ -70,12 +71,8 @@ def test_fixtures_present_and_from_the_reference():
 def test_oracle_reproduces_the_reference(path):
     z, sc, sd, c3 = load_case(path)
     depth = bool(z["render_depth"])
-    orc.set_flag("ieee_depth", 1)
-    try:
-        f = orc.forward_scene(sc, sd, cov3D_precomp=c3, render_depth=depth)
-        g = None if depth else f.backward(sc.dL_dout)
-    finally:
-        orc.set_flag("ieee_depth", 0)
+    f = orc.forward_scene(sc, sd, cov3D_precomp=c3, render_depth=depth)
+    g = None if depth else f.backward(sc.dL_dout)
     # ---- integer / index results: exact
     assert f.num_rendered == int(z["num_rendered"])
     assert np.array_equal(f.radii, z["radii"])
@@ -121,12 +118,16 @@ def test_oracle_reproduces_the_reference(path):
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=[os.path.basename(p)[:-4] for p in FIXTURES])
-def test_default_fma_depth_keys_stay_within_rounding_of_the_reference(path):
-    """The oracle's default depthAlongRay (fused multiply-adds, the order the HIP kernels share) against the same
-    fixtures: depth keys within a few ulp, the sorted list equal up to a handful of neighbour swaps, image >= 60 dB."""
+def test_fma_depth_keys_stay_within_rounding_of_the_reference(path):
+    """The oracle's fused-multiply-add depthAlongRay (switch ieee_depth=0, the order libstp_raster_fma.so shares) against the
+    same fixtures: depth keys within a few ulp, the sorted list equal up to a handful of neighbour swaps, image >= 60 dB."""
     z, sc, sd, c3 = load_case(path)
     depth = bool(z["render_depth"])
-    f = orc.forward_scene(sc, sd, cov3D_precomp=c3, render_depth=depth)
+    orc.set_flag("ieee_depth", 0)
+    try:
+        f = orc.forward_scene(sc, sd, cov3D_precomp=c3, render_depth=depth)
+    finally:
+        orc.set_flag("ieee_depth", 1)
     assert f.num_rendered == int(z["num_rendered"]) and np.array_equal(f.radii, z["radii"])
     if f.num_rendered:
         ka, kb = f.array("keys"), z["keys"]
