@@ -275,7 +275,7 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
     R = int(o1[0])
     B = 0
     if recording or mode in (0, 2):   # n_contrib = blends per pixel (recording forwards), list positions visited (GLOBAL / k-buffer)
-        B = int(_C.image_array(o1[5], scene.W, scene.H, "n_contrib").to(torch.int64).clamp_(max=256 if recording else 1 << 30).sum().item())
+        B = int(_C.image_array(o1[5], scene.W, scene.H, "n_contrib").to(torch.int64).sum().item())
     _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
     del o1
     M = 16

@@ -28,8 +28,9 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 5
+#define STP_ABI_VERSION 6
 #define STP_GRAD_RECORD_FLOATS 16 /* floats per Gaussian in grad_records (see stp_backward) */
+#define STP_GRAD_RECORD_USED 9    /* of which these carry data; the record stride of stp_backward_phases' compact form (phases bit 2) */
 
 /* Replaces CudaRasterizer::SplattingSettings + SortSettings + SortQueueSizes + CullingSettings
    (rasterizer.h:27-135) and their json parser (rasterizer.h:160-182): the host binding fills this
@@ -140,7 +141,10 @@ int stp_backward(int P, int D, int M, int R,
    phases bit 0 = BACKWARD::render (rasterizer_impl.cu:474-495): accumulates the per-Gaussian partial
    sums of THIS rank's tile rows into grad_records (nothing else is written);
    phases bit 1 = BACKWARD::preprocess (rasterizer_impl.cu:501-525): consumes grad_records (after the
-   caller has summed them across ranks) and writes every dL_d* output.  phases = 3 == stp_backward. */
+   caller has summed them across ranks) and writes every dL_d* output.  phases = 3 == stp_backward.
+   phases bit 2 (value 4, with bit 0 and / or bit 1) = COMPACT records: grad_records is P x STP_GRAD_RECORD_USED floats (36 bytes per
+   Gaussian, no padding) -- the buffer a tile-row shard all-reduces between the two halves crosses xGMI as it is, without a
+   pack / unpack copy on either side.  (The padded 64-byte record is what a single GPU wants: one line, one atomic request per flush.) */
 int stp_backward_phases(int phases, int P, int D, int M, int R,
                         const float* background, int width, int height,
                         const StpSettings* settings,
@@ -175,6 +179,22 @@ size_t stp_blend_log_bytes(int width, int height);
    image names   : final_T n_contrib ranges */
 int stp_geometry_layout(int P, const StpSettings* settings, const char* name, size_t* offset, size_t* count);
 int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count);
+/* The entry count a binning buffer was carved with by the forward that last used it: num_rendered, or -- for a run-ahead forward, which
+   carves and launches before num_rendered is known -- the capacity it guessed (>= num_rendered; the first num_rendered elements of
+   every sub-array are the valid ones).  Pass the result to stp_binning_layout.  R is the fallback for a pointer no forward of this
+   process has carved.  stp_backward does this lookup itself: callers keep passing (buffer, num_rendered) as in the reference. */
+int stp_binning_layout_count(const void* binning_buffer, int R);
+/* Forgets the per-device size guesses (tile-list entries of the previous frames of each kind) that the run-ahead forward and the early
+   binning request are sized by: the next forward of every kind takes the reference's path again (hand-over in the middle of the frame,
+   exact request).  For tests and benchmarks that want a defined starting state; never needed for correctness. */
+void stp_reset_size_guesses(void);
+/* Run-ahead forward (off by default; STP_RUN_AHEAD=1 in the environment switches it on at load time).  With it, every forward that has a
+   size guess (i.e. every forward but the first of its kind) enqueues ALL its kernels on the guessed capacity before it reads num_rendered
+   back -- no host wait in the middle of the frame; a frame that does not fit its guess is redone with the exact size before stp_forward
+   returns.  Results are identical either way (keys, lists, image, gradients).  Measured on MI355X it costs 0.5 % at C2 (the padded
+   entries pass through the device-wide sort) and is therefore an option: for hosts whose launching thread is stalled often. */
+void stp_set_run_ahead(int enabled);
+int stp_get_run_ahead(void);
 int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count);
 
 /* Stage timer, the counterpart of the reference's `Timer` (rasterizer_impl.h:77-147; stages

@@ -264,9 +264,10 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     const int H = (int)dL_dout_color.size(1), W = (int)dL_dout_color.size(2);
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
     const auto fopt = means3D.options().dtype(torch::kFloat32);
-    torch::Tensor records = partial.has_value() ? *partial : torch::zeros({P, STP_GRAD_RECORD_FLOATS}, fopt);
-    TORCH_CHECK(records.dim() == 2 && records.size(0) == P && records.size(1) == STP_GRAD_RECORD_FLOATS && records.scalar_type() == torch::kFloat32 &&
-                    records.is_contiguous(), "partial must be a contiguous float32 (P,", STP_GRAD_RECORD_FLOATS, ") tensor");
+    const int rec_floats = (phases & 4) ? STP_GRAD_RECORD_USED : STP_GRAD_RECORD_FLOATS; // (bit 2: compact records, the tile-row shard's wire format)
+    torch::Tensor records = partial.has_value() ? *partial : torch::zeros({P, rec_floats}, fopt);
+    TORCH_CHECK(records.dim() == 2 && records.size(0) == P && records.size(1) == rec_floats && records.scalar_type() == torch::kFloat32 &&
+                    records.is_contiguous(), "partial must be a contiguous float32 (P,", rec_floats, ") tensor");
     torch::Tensor dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
     if (phases & 2) {
         // the per-Gaussian half writes every row of its outputs (zeros for invisible Gaussians): no zero-fill needed,
@@ -296,7 +297,7 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                                            (void*)stream);
         if (rc < 0) raise_last(rc);
     }
-    if (phases == 1) return {records};
+    if ((phases & 3) == 1) return {records};
     return {dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations};
 }
 

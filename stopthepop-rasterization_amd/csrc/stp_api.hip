@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 
 namespace stp {
 
@@ -144,13 +145,21 @@ GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total,
     return g;
 }
 
-ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* total, NamedOffset* names, int* n_names)
+// The image-side state covers the frame's TILE-ROW WINDOW only (StpSettings::tile_y0 / tile_y1; the whole frame by default): a rank of a
+// tile-row shard holds 1 / N of the per-pixel arrays and of the blend log (4.3 GB per frame at 4K), not the whole frame's.  The kernels keep
+// indexing by frame coordinates (pixel id W * y + x, tile id gx * ty + tx): the sub-array pointers handed to them are shifted back by the
+// window's first pixel row / tile, so that index -> address is unchanged inside the window and nothing outside it is ever touched (every
+// loop over tiles runs over [gx * ty0, gx * ty1), every kernel's grid over the window's tiles).
+ImageState carve_image(char* base, int W, int H, int ty0, int ty1, bool with_log, size_t* total, NamedOffset* names, int* n_names)
 {
     Carver c(base);
     ImageState s{};
     size_t off;
     int n = 0;
     auto note = [&](const char* nm, size_t o, size_t cnt) { if (names) names[n] = {nm, o, cnt}; n++; };
+    const int gx = (W + TILE - 1) / TILE;
+    const int py0 = ty0 * TILE < H ? ty0 * TILE : H, py1 = ty1 * TILE < H ? ty1 * TILE : H;
+    const size_t N = (size_t)W * (size_t)(py1 > py0 ? py1 - py0 : 0), T = (size_t)gx * (size_t)(ty1 > ty0 ? ty1 - ty0 : 0);
     s.final_T = c.take<float>(N, &off); note("final_T", off, N);
     s.n_contrib = c.take<uint32_t>(N, &off); note("n_contrib", off, N);
     s.ranges = c.take<uint2>(T, &off); note("ranges", off, 2 * T);
@@ -162,12 +171,19 @@ ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* to
     // that is (wrongly) told a log exists -- e.g. after a render_depth forward -- replays nothing and re-sorts every tile
     // instead of reading a log that was never allocated.
     s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
-    if (with_log) { // blend log of the recording forward: [tile][wave][record][lane], 256 records of 2 bytes per pixel
-        const size_t recs = T * 4 * (size_t)blend_log_rows() * 64; // T x 4 waves x rows x 64 lanes, 2 B each
+    const size_t recs_per_tile = 4 * (size_t)blend_log_rows() * 64; // 4 waves x rows x 64 lanes, 2 B each
+    if (with_log) { // blend log of the recording forward: [tile][wave][record][lane]
+        const size_t recs = T * recs_per_tile;
         s.blend_log = c.take<uint32_t>(recs / 2, &off); note("blend_log", off, recs);
     }
     if (total) *total = c.total();
     if (n_names) *n_names = n;
+    if (base) { // frame-coordinate indexing (see above)
+        const size_t pix0 = (size_t)W * (size_t)py0, tile0 = (size_t)gx * (size_t)ty0;
+        s.final_T -= pix0; s.n_contrib -= pix0;
+        s.ranges -= tile0; s.tile_counts -= tile0; s.tile_cursor -= tile0; s.tile_flags -= tile0;
+        if (s.blend_log) s.blend_log -= tile0 * (recs_per_tile / 2);
+    }
     return s;
 }
 
@@ -313,6 +329,27 @@ inline void cpu_relax()
 #endif
 }
 
+// Which entry count a binning buffer was CARVED with.  A run-ahead forward (stp_forward) carves and launches on a capacity before
+// num_rendered is known; the sub-arrays of the buffer then sit at the offsets of that capacity, not of the count stp_forward returns.  The
+// backward and the introspection helpers are handed (pointer, num_rendered), as in the reference: they look the pointer up here
+// (stp_binning_layout_count).  One entry per live buffer address, overwritten whenever a forward carves that address again.
+std::mutex g_layout_mutex;
+std::unordered_map<const void*, uint32_t> g_layout;
+void remember_layout(const void* binning, uint32_t count)
+{
+    std::lock_guard<std::mutex> l(g_layout_mutex);
+    if (g_layout.size() > 8192 && g_layout.find(binning) == g_layout.end()) g_layout.erase(g_layout.begin()); // (thousands of forwards whose buffers nobody reused)
+    g_layout[binning] = count;
+}
+uint32_t layout_of(const void* binning, uint32_t R)
+{
+    std::lock_guard<std::mutex> l(g_layout_mutex);
+    const auto it = g_layout.find(binning);
+    return it != g_layout.end() && it->second >= R ? it->second : R;
+}
+
+std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && e[0] == '1') ? 1 : 0; }()};
+
 int acquire_mailbox(Mailbox* out)
 {
     int device = 0;
@@ -362,19 +399,29 @@ size_t stp_binning_buffer_size(int R)
 size_t stp_image_buffer_size(int width, int height)
 {
     size_t total = 0;
-    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-    carve_image(nullptr, (size_t)width * height, T, false, &total);
+    carve_image(nullptr, width, height, 0, (height + TILE - 1) / TILE, false, &total);
     return total;
 }
 
-size_t stp_blend_log_bytes(int width, int height)
+static void clamp_rows(int height, int& y0, int& y1) // the window fill_frame derives from StpSettings::tile_y0 / tile_y1
 {
-    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+    const int gy = (height + TILE - 1) / TILE;
+    if (y1 <= 0) { y0 = 0; y1 = gy; return; }
+    y0 = y0 < 0 ? 0 : (y0 > gy ? gy : y0);
+    y1 = y1 > gy ? gy : y1;
+    if (y1 < y0) y1 = y0;
+}
+
+size_t stp_blend_log_bytes_rows(int width, int height, int tile_y0, int tile_y1)
+{
+    clamp_rows(height, tile_y0, tile_y1);
     size_t plain = 0, with_log = 0;
-    carve_image(nullptr, (size_t)width * height, T, false, &plain);
-    carve_image(nullptr, (size_t)width * height, T, true, &with_log);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, false, &plain);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, true, &with_log);
     return with_log - plain;
 }
+
+size_t stp_blend_log_bytes(int width, int height) { return stp_blend_log_bytes_rows(width, height, 0, 0); }
 
 static int find_name(const NamedOffset* names, int n, const char* name, size_t* offset, size_t* count)
 {
@@ -398,12 +445,27 @@ int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count)
     carve_binning(nullptr, (size_t)(R > 0 ? R : 0), nullptr, names, &n);
     return find_name(names, n, name, offset, count);
 }
-int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count)
+void stp_set_run_ahead(int enabled) { g_run_ahead.store(enabled ? 1 : 0, std::memory_order_relaxed); }
+int stp_get_run_ahead(void) { return g_run_ahead.load(std::memory_order_relaxed); }
+void stp_reset_size_guesses(void)
+{
+    for (auto& dev : g_guess)
+        for (auto& slot : dev) { slot.key.store(0, std::memory_order_release); slot.R.store(0u, std::memory_order_relaxed); }
+}
+int stp_binning_layout_count(const void* binning_buffer, int R)
+{
+    return (int)layout_of(binning_buffer, (uint32_t)(R > 0 ? R : 0));
+}
+int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const char* name, size_t* offset, size_t* count)
 {
     NamedOffset names[16]; int n = 0;
-    const size_t T = (size_t)((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-    carve_image(nullptr, (size_t)width * height, T, true, nullptr, names, &n);
+    clamp_rows(height, tile_y0, tile_y1);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, true, nullptr, names, &n);
     return find_name(names, n, name, offset, count);
+}
+int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count)
+{
+    return stp_image_layout_rows(width, height, 0, 0, name, offset, count);
 }
 
 void stp_timing_enable(int enabled)
@@ -492,13 +554,13 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     GeometryState g = carve_geometry(geom_ptr, (size_t)P, with_inv, nullptr);
     if (!radii) radii = g.internal_radii;
 
-    const size_t N = (size_t)width * height, T = (size_t)f.gx * f.gy;
+    const size_t T = (size_t)f.gx * f.gy;
     size_t img_bytes = 0;
     const bool with_log = uses_blend_log(*settings);
-    carve_image(nullptr, N, T, with_log, &img_bytes);
+    carve_image(nullptr, width, height, f.ty0, f.ty1, with_log, &img_bytes); // (the tile-row window's share: see carve_image)
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
-    ImageState img = carve_image(img_ptr, N, T, with_log, nullptr);
+    ImageState img = carve_image(img_ptr, width, height, f.ty0, f.ty1, with_log, nullptr);
 
     // How the (tile, depth) order is established:
     //   default           device-wide radix sort on the tile bits only (two passes), then the tile's own workgroup sorts its
@@ -521,7 +583,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
 
     g_timer.begin_forward();
     g_timer.mark(0, st);
-    STP_TRY(launch_frame_init(g, img, (int)T, with_log, atomic_bin, st), "frame init launch");
+    STP_TRY(launch_frame_init(g, img, f.gx * f.ty0, f.gx * (f.ty1 - f.ty0), with_log, atomic_bin, st), "frame init launch");
     STP_TRY(launch_preprocess(f, g, radii, atomic_bin ? img.tile_counts : nullptr, st), "preprocess launch");
     STP_DEBUG_SYNC("preprocess");
     if (!two_level_scan) STP_TRY(launch_scan(f, g, st), "inclusive scan");
@@ -561,19 +623,35 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     if (side) {
         if (!colour_late) { if (int rc = colour_on_side()) return rc; }
     } else STP_TRY(launch_sh_color(f, g, radii, st), "SH colour launch");
-    // the binning buffer is requested BEFORE the wait, sized by the count of the previous frame of the same kind on this
-    // device (+12.5 %): in the steady state of training or serving no allocator callback runs between the kernels.  The
-    // exact-size request of the reference follows only when the guess was too small (STP_BINNING=exact: always) -- so
-    // binning_alloc may be called TWICE per forward, the second time with the larger size (include/stp_raster.h).
+    // The binning buffer is requested BEFORE num_rendered is known, sized by the counts of the previous frames of the same kind on this
+    // device (+12.5 %): in the steady state of training or serving no allocator callback runs between the kernels.  The exact-size
+    // request of the reference follows only when the guess was too small (STP_BINNING=exact: always) -- so binning_alloc may be called
+    // TWICE per forward, the second time with the larger size (include/stp_raster.h).
     static const char* const bin_env = std::getenv("STP_BINNING");
     static const bool speculative = !(bin_env && std::strcmp(bin_env, "exact") == 0);
+    // RUN-AHEAD (round 4; off by default: STP_RUN_AHEAD=1 in the environment or stp_set_run_ahead(1) switch it on).  The reference -- and the
+    // default path here -- stop the host after the scan until num_rendered has come back, and only then enqueue duplicate / sort / render:
+    // a stall of the launching thread there is GPU idle time.  With a size guess the whole forward is enqueued at once ON THE GUESSED
+    // CAPACITY: the sub-arrays are carved for `cap` entries, duplicate_kernel guards its writes and pads [num_rendered, cap) with entries
+    // that sort behind every tile, the sort / range passes run over `cap`, the render kernels are the ones for a tame Sigma^-1 -- and the
+    // host reads the mailbox AFTER the last launch, when the word has long arrived.  Only a frame that does not fit (or whose status word
+    // asks for the checked reciprocal) is redone from duplicate_kernel on with the exact size, before the call returns: results never
+    // depend on the guess (tests/test_gpu_parity.py::test_run_ahead_overflow_is_redone; every GpuRun of the tests renders its frame both ways).
+    // MEASURED (one box, alternating, profiles/r04_run_ahead_ab.txt): the padding costs the device-wide passes what it weighs -- C2-full sort
+    // stage 0.325 -> 0.343 ms, step 2.410 -> 2.422 ms; C5 +0.04 ms; C4 +0.03 ms -- and nothing comes back: the hand-over bubble was already
+    // hidden (mailbox word + colour kernel behind it), `ms_per_step - sum(stages)` stays at 0.04 ms, and C1 is bound by the ~25 launches of a
+    // step, not by the round trip.  Hence off by default; what it does buy is a frame whose GPU time no longer depends on the launching
+    // thread being scheduled in the middle of it.
+    const bool run_ahead = g_run_ahead.load(std::memory_order_relaxed) != 0;
     size_t bin_have = 0;
     char* bin_ptr = nullptr;
     const uint64_t gkey = guess_key(f);
     SizeGuess& gslot = g_guess[mb.device][(gkey >> 1) % GUESS_SLOTS];
     const uint32_t guess = (speculative && gslot.key.load(std::memory_order_acquire) == gkey) ? gslot.R.load(std::memory_order_relaxed) : 0u;
+    const bool ahead = run_ahead && guess > 0 && two_level_scan && !atomic_bin && !debug;
+    const uint32_t cap = guess + guess / 8 + (ahead ? 1024u : 0u);
     if (guess > 0) {
-        carve_binning(nullptr, (size_t)guess + guess / 8, &bin_have);
+        carve_binning(nullptr, (size_t)cap, &bin_have);
         bin_ptr = (char*)binning_alloc(binning_user, bin_have);
         if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
     }
@@ -582,66 +660,104 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // polled now and then: it completes if the kernel has, and it is how a device fault surfaces (STP_MAILBOX=event: wait on the event only).
     static const char* const mbx_env = std::getenv("STP_MAILBOX");
     static const bool mbx_spin = !(mbx_env && std::strcmp(mbx_env, "event") == 0);
-    if (mbx_spin) {
-        for (unsigned it = 1;; it++) {
-            if (mb.host[2] == mb.ticket) break;
-            if ((it & 255u) == 0u) {
-                const hipError_t q = hipEventQuery(mb.ev);
-                if (q == hipSuccess) break;
-                if (q != hipErrorNotReady) return fail_hip(q, "query (num_rendered)");
-                if (it > (1u << 22)) { STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)"); break; } // (seconds of spinning: stop burning a core)
+    auto wait_mailbox = [&]() -> int {
+        if (mbx_spin) {
+            for (unsigned it = 1;; it++) {
+                if (mb.host[2] == mb.ticket) break;
+                if ((it & 255u) == 0u) {
+                    const hipError_t q = hipEventQuery(mb.ev);
+                    if (q == hipSuccess) break;
+                    if (q != hipErrorNotReady) return fail_hip(q, "query (num_rendered)");
+                    if (it > (1u << 22)) { STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)"); break; } // (seconds of spinning: stop burning a core)
+                }
+                cpu_relax();
             }
-            cpu_relax();
+            std::atomic_thread_fence(std::memory_order_acquire);
+        } else STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");
+        return 0;
+    };
+    // everything behind the hand-over: duplicate -> (colour kernel on the side stream) -> sort -> ranges -> per-tile sort + gather -> render.
+    // L = entries the device-wide passes run over: num_rendered, or the capacity of a run-ahead launch (dup_cap = the same value then)
+    bool colour_started = !(side && colour_late);
+    auto binning_and_render = [&](const GeometryState& gd, const BinningState& b, int L, uint32_t dup_cap) -> int {
+        STP_TRY(launch_duplicate(f, gd, radii, b, atomic_bin ? img.tile_cursor : nullptr, dup_cap, st), "duplicate launch");
+        STP_DEBUG_SYNC("duplicate");
+        g_timer.mark(2, st);
+        if (!colour_started) {
+            STP_TRY(hipEventRecord(mb.ev, st), "record event behind duplicate");
+            if (int rc = colour_on_side()) return rc;
+            colour_started = true;
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
-    } else STP_TRY(hipEventSynchronize(mb.ev), "synchronize (num_rendered)");
-    const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
-    if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
-    f.wild_cov = (host_status[1] & 2u) ? 1 : 0;
-    const int R = (int)host_status[0];
-    gslot.R.store((uint32_t)R, std::memory_order_relaxed);
-    gslot.key.store(gkey, std::memory_order_release);
-    STP_DEBUG_SYNC("SH colour");
-    g_timer.mark(1, st);
+        if (atomic_bin) {
+            STP_TRY(launch_bin_pad(b, img, L, st), "pad entries");
+        } else {
+            STP_TRY(launch_sort(f, b, L, tile_local_sort, st), "radix sort");
+            STP_DEBUG_SYNC("sort");
+            STP_TRY(launch_ranges(f, b, img, L, st), "tile ranges");
+            STP_DEBUG_SYNC("ranges");
+        }
+        STP_TRY(colours.join(), "join colour stream"); // (the entry gather -- or, in GLOBAL mode, the render kernel -- reads the colours)
+        if (tile_local_sort) STP_TRY(launch_tile_sort_gather(f, g, b, img, L, atomic_bin, st), "tile sort + entry gather");
+        else STP_TRY(launch_gather_entries(f, g, b, L, st), "entry gather");
+        STP_DEBUG_SYNC("entry gather");
+        g_timer.mark(3, st);
+        std::string err;
+        hipError_t e = launch_render_forward(f, g, b, img, out_color, st, &err);
+        if (e != hipSuccess) {
+            if (!err.empty()) return fail(STP_ERR_QUEUE_SIZE, err);
+            return fail_hip(e, "render launch");
+        }
+        STP_DEBUG_SYNC("render");
+        STP_TRY(launch_render_debug_finish(f, img, out_color, st), "debug visualisation");
+        g_timer.mark(4, st);
+        return 0;
+    };
+    auto read_mailbox = [&](int* R_out, bool* wild_out) -> int {
+        if (int rc = wait_mailbox()) return rc;
+        const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
+        if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
+        *wild_out = (host_status[1] & 2u) != 0;
+        *R_out = (int)host_status[0];
+        // next frame's guess: this frame's count, but never less than 31/32 of the last guess -- with a moving camera the count jumps from
+        // frame to frame, and a guess that follows every dip overflows at the next peak (a redone frame costs far more than padding)
+        const uint32_t prev = gslot.key.load(std::memory_order_acquire) == gkey ? gslot.R.load(std::memory_order_relaxed) : 0u;
+        const uint32_t keep = run_ahead ? prev - prev / 32 : 0u;
+        gslot.R.store((uint32_t)*R_out > keep ? (uint32_t)*R_out : keep, std::memory_order_relaxed);
+        gslot.key.store(gkey, std::memory_order_release);
+        return 0;
+    };
 
+    int R = 0;
+    bool wild = false;
+    GeometryState g_dup = g; // what duplicate_kernel sees (a redone frame finds the finished scan in point_offsets: no second level)
+    if (ahead) {
+        f.wild_cov = 0; // (every sane frame; the status word says otherwise afterwards)
+        g_timer.mark(1, st);
+        const BinningState b = carve_binning(bin_ptr, (size_t)cap, nullptr);
+        if (int rc = binning_and_render(g_dup, b, (int)cap, cap)) return rc;
+        if (int rc = read_mailbox(&R, &wild)) return rc;
+        if ((uint32_t)R <= cap && !wild) {
+            remember_layout(bin_ptr, cap);
+            return R;
+        }
+        // the frame did not fit its guess (or needs the checked reciprocal): once more from duplicate_kernel on, exact this time
+        g_dup.block_prefix = nullptr; g_dup.block_sums = nullptr;
+        STP_TRY(launch_frame_init(g, img, f.gx * f.ty0, f.gx * (f.ty1 - f.ty0), with_log, atomic_bin, st), "frame init launch"); // ranges and tile flags of the discarded pass
+    } else {
+        if (int rc = read_mailbox(&R, &wild)) return rc;
+        STP_DEBUG_SYNC("SH colour");
+        g_timer.mark(1, st);
+    }
+    f.wild_cov = wild ? 1 : 0;
     size_t bin_bytes = 0;
     carve_binning(nullptr, (size_t)R, &bin_bytes);
     if (bin_bytes > bin_have) {
         bin_ptr = (char*)binning_alloc(binning_user, bin_bytes);
         if (!bin_ptr) return fail(STP_ERR_ALLOC, "binning allocator returned NULL");
     }
-    BinningState b = carve_binning(bin_ptr, (size_t)R, nullptr);
-
-    STP_TRY(launch_duplicate(f, g, radii, b, atomic_bin ? img.tile_cursor : nullptr, st), "duplicate launch");
-    STP_DEBUG_SYNC("duplicate");
-    g_timer.mark(2, st);
-    if (side && colour_late) {
-        STP_TRY(hipEventRecord(mb.ev, st), "record event behind duplicate");
-        if (int rc = colour_on_side()) return rc;
-    }
-    if (atomic_bin) {
-        STP_TRY(launch_bin_pad(b, img, R, st), "pad entries");
-    } else {
-        STP_TRY(launch_sort(f, b, R, tile_local_sort, st), "radix sort");
-        STP_DEBUG_SYNC("sort");
-        STP_TRY(launch_ranges(f, b, img, R, st), "tile ranges");
-        STP_DEBUG_SYNC("ranges");
-    }
-    STP_TRY(colours.join(), "join colour stream"); // (the entry gather -- or, in GLOBAL mode, the render kernel -- reads the colours)
-    if (tile_local_sort) STP_TRY(launch_tile_sort_gather(f, g, b, img, R, atomic_bin, st), "tile sort + entry gather");
-    else STP_TRY(launch_gather_entries(f, g, b, R, st), "entry gather");
-    STP_DEBUG_SYNC("entry gather");
-    g_timer.mark(3, st);
-
-    std::string err;
-    hipError_t e = launch_render_forward(f, g, b, img, out_color, st, &err);
-    if (e != hipSuccess) {
-        if (!err.empty()) return fail(STP_ERR_QUEUE_SIZE, err);
-        return fail_hip(e, "render launch");
-    }
-    STP_DEBUG_SYNC("render");
-    STP_TRY(launch_render_debug_finish(f, img, out_color, st), "debug visualisation");
-    g_timer.mark(4, st);
+    const BinningState b = carve_binning(bin_ptr, (size_t)R, nullptr);
+    if (int rc = binning_and_render(g_dup, b, R, 0xFFFFFFFFu)) return rc;
+    if (bin_ptr) remember_layout(bin_ptr, (uint32_t)R);
     return R;
 }
 
@@ -668,12 +784,13 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
                rotations, cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, cam_pos, tan_fovx, tan_fovy, 0);
     const bool with_inv = requires_depth_along_ray(*settings);
     GeometryState g = carve_geometry(geom_buffer, (size_t)P, with_inv, nullptr);
-    BinningState b = carve_binning(binning_buffer, (size_t)(R > 0 ? R : 0), nullptr);
-    ImageState img = carve_image(image_buffer, (size_t)width * height, (size_t)f.gx * f.gy, uses_blend_log(*settings), nullptr);
+    BinningState b = carve_binning(binning_buffer, (size_t)layout_of(binning_buffer, (uint32_t)(R > 0 ? R : 0)), nullptr); // (a run-ahead forward carved it for its capacity)
+    ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, uses_blend_log(*settings), nullptr);
     if (!radii) radii = g.internal_radii;
 
     BackwardParams bw;
     bw.pixel_colors = pixel_colors; bw.dL_dpix = dL_dpix; bw.dL_dmean2D = dL_dmean2D; bw.grad_rec = grad_records;
+    bw.grad_stride = (phases & 4) ? STP_GRAD_RECORD_USED : STP_GRAD_RECORD_FLOATS;
     bw.dL_dopacity = dL_dopacity; bw.dL_dcolor = dL_dcolor; bw.dL_dmean3D = dL_dmean3D; bw.dL_dcov3D = dL_dcov3D; bw.dL_dsh = dL_dsh;
     bw.dL_dscale = dL_dscale; bw.dL_drot = dL_drot;
 

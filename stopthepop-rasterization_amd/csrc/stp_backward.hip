@@ -30,7 +30,8 @@ struct BwdPreArgs {
     const float* view;
     const float* proj;
     const float* cam;
-    const float* grad_rec; // P x 16: sums of the render half (layout: stp_raster.h, stp_backward)
+    const float* grad_rec; // P x grad_stride: sums of the render half (layout: stp_raster.h, stp_backward)
+    int grad_stride;       // 16 (one line per Gaussian, two 16-byte loads) or 9 (compact records of a tile-row shard)
     float* dL_dmean2D;     // P x 3  (out)
     float* dL_dopacity;    // P      (out)
     float* dL_dcolor;      // P x 3  (out)
@@ -50,9 +51,18 @@ __device__ __forceinline__ void gaussian_backward(const BwdPreArgs& a, int idx, 
     const float3 mean = make_float3(a.means3D[3 * (size_t)idx], a.means3D[3 * (size_t)idx + 1], a.means3D[3 * (size_t)idx + 2]);
     float3 dmean;
     // the render half's sums: one 64-byte record, two 16-byte loads and a scalar
-    const float4 rec0 = *reinterpret_cast<const float4*>(a.grad_rec + 16 * (size_t)idx);     // colour r g b, mean2D x
-    const float4 rec1 = *reinterpret_cast<const float4*>(a.grad_rec + 16 * (size_t)idx + 4); // mean2D y, conic xx xy yy
-    const float rec_op = a.grad_rec[16 * (size_t)idx + 8];
+    float4 rec0, rec1; // colour r g b, mean2D x | mean2D y, conic xx xy yy
+    float rec_op;
+    if (a.grad_stride == 16) {
+        rec0 = *reinterpret_cast<const float4*>(a.grad_rec + 16 * (size_t)idx);
+        rec1 = *reinterpret_cast<const float4*>(a.grad_rec + 16 * (size_t)idx + 4);
+        rec_op = a.grad_rec[16 * (size_t)idx + 8];
+    } else { // compact records: 36-byte stride, scalar loads
+        const float* __restrict__ r = a.grad_rec + (size_t)a.grad_stride * idx;
+        rec0 = make_float4(r[0], r[1], r[2], r[3]);
+        rec1 = make_float4(r[4], r[5], r[6], r[7]);
+        rec_op = r[8];
+    }
     a.dL_dcolor[3 * (size_t)idx] = rec0.x; a.dL_dcolor[3 * (size_t)idx + 1] = rec0.y; a.dL_dcolor[3 * (size_t)idx + 2] = rec0.z;
     a.dL_dmean2D[3 * (size_t)idx] = rec0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = rec1.x;
 
@@ -346,7 +356,7 @@ hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState&
     a.means3D = f.means3D; a.radii = radii; a.shs = f.shs; a.clamped = g.clamped; a.opacities = f.opacities; a.scales = f.scales;
     a.rotations = f.rotations; a.cov3Ds = f.cov3D_precomp ? f.cov3D_precomp : g.cov3D; // reference rasterizer_impl.cu:500
     a.view = f.viewmatrix; a.proj = f.projmatrix; a.cam = f.cam_pos;
-    a.dL_dmean2D = bw.dL_dmean2D; a.grad_rec = bw.grad_rec; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
+    a.dL_dmean2D = bw.dL_dmean2D; a.grad_rec = bw.grad_rec; a.grad_stride = bw.grad_stride; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
     a.dL_dmean3D = bw.dL_dmean3D; a.dL_dcov3D = bw.dL_dcov3D; a.dL_dsh = bw.dL_dsh; a.dL_dscale = bw.dL_dscale; a.dL_drot = bw.dL_drot;
     const size_t lds = (a.shs != nullptr && a.M > 0) ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
     if (lds > 64 * 1024) { // above the default dynamic-LDS limit (M > 21: no SH degree the reference knows)

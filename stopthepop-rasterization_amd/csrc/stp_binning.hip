@@ -68,9 +68,12 @@ namespace {
 
 constexpr int SCAN_THREADS = 1024;
 
-__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int T, const uint32_t* __restrict__ counts, uint2* __restrict__ ranges,
-                                                                 uint32_t* __restrict__ cursor, uint32_t* __restrict__ total)
+__global__ void __launch_bounds__(SCAN_THREADS) tile_scan_kernel(int tile0, int T, const uint32_t* __restrict__ counts_, uint2* __restrict__ ranges_,
+                                                                 uint32_t* __restrict__ cursor_, uint32_t* __restrict__ total)
 {
+    const uint32_t* __restrict__ counts = counts_ + tile0; // the T tiles of the frame's tile-row window
+    uint2* __restrict__ ranges = ranges_ + tile0;
+    uint32_t* __restrict__ cursor = cursor_ + tile0;
     __shared__ uint32_t s_part[SCAN_THREADS];
     const int tid = (int)threadIdx.x;
     const int per = (T + SCAN_THREADS - 1) / SCAN_THREADS;
@@ -108,7 +111,7 @@ __global__ void __launch_bounds__(256) bin_pad_kernel(int R, const uint32_t* __r
 
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st)
 {
-    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, f.gx * f.gy, img.tile_counts, img.ranges, img.tile_cursor, img.bin_total);
+    hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, f.gx * f.ty0, f.gx * (f.ty1 - f.ty0), img.tile_counts, img.ranges, img.tile_cursor, img.bin_total);
     return hipGetLastError();
 }
 

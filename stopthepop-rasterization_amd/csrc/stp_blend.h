@@ -32,7 +32,8 @@ struct RenderArgs {
     // backward inputs / outputs
     const float* pixel_colors;
     const float* dL_dpix;
-    float* grad_rec;   // P x GRAD_REC floats: the nine sums of a Gaussian in one 64-byte record (stp_raster.h, stp_backward)
+    float* grad_rec;   // P x grad_stride floats: the nine sums of a Gaussian in one record (stp_raster.h, stp_backward)
+    int grad_stride;   // floats per record: STP_GRAD_RECORD_FLOATS (one 64-byte line), or 9 = compact (tile-row sharding: what crosses xGMI)
     // blend log (training forward -> replay backward): per (tile, wave, k, lane) the list position of the k-th
     // entry that lane's pixel blended; tile_flags[tile] != 0 marks a tile whose log overflowed
     uint32_t* blend_log;   // (storage; the records are log_t)
@@ -51,7 +52,15 @@ constexpr int LOG_MAX_LIST = 65535;
 #ifndef STP_LOG_PACK
 #define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured)
 #endif
-constexpr int BLEND_LOG_DEPTH = 256; // records per pixel the log can hold (2 B each: 512 B per pixel)
+#ifndef STP_LOG_DEPTH
+#define STP_LOG_DEPTH 208 // records per pixel the log can hold (2 B each; with the spare row 418 B per pixel of the tile grid).  256 until round 3.  The
+                          // blends per pixel of the BASELINE frames (profiles/r03_log_depth_stats.txt): C2 mean 65 / max 114, C3 99 / 155, C5 109 / 195.
+                          // MEASURED with 192 (round 4, profiles/r04_log_depth_ab.txt): C2 and C3 unchanged -- write traffic does not depend on the
+                          // depth, only written records cost -- but ONE tile of C5 overflows, and that one tile, re-sorted by a single workgroup
+                          // (the fallback of every overflow), takes 1.25 ms: backward render 1.54 -> 2.79 ms, 154 -> 129 frames/s.  A depth is
+                          // a cliff, not a slope: 208 is the smallest multiple of 16 that holds all five BASELINE frames (19 % less log than 256).
+#endif
+constexpr int BLEND_LOG_DEPTH = STP_LOG_DEPTH;
 #ifndef STP_LOG_UNCOND
 #define STP_LOG_UNCOND 1 // 1: the hierarchical recording forward stores a record in EVERY head step, without a branch -- a step that does
                          // not blend writes into the slot of the lane's next record, which the next blend overwrites -- and only the
@@ -182,7 +191,7 @@ __device__ __forceinline__ bool blend_backward_terms(BwdPixel& b, const RenderAr
 constexpr int GRAD_REC = STP_GRAD_RECORD_FLOATS;
 __device__ __forceinline__ float* grad_slot(const RenderArgs& a, int id, int k)
 {
-    return a.grad_rec + (size_t)GRAD_REC * id + k;
+    return a.grad_rec + (size_t)a.grad_stride * id + k;
 }
 
 // Straightforward accumulation: nine hardware fp32 atomics (global_atomic_add_f32; build with

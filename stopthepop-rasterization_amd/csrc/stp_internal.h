@@ -115,7 +115,7 @@ struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
 struct NamedOffset { const char* name; size_t offset; size_t count; };
 
 GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
-ImageState carve_image(char* base, size_t N, size_t T, bool with_log, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
+ImageState carve_image(char* base, int W, int H, int ty0, int ty1, bool with_log, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr); // the tile-row window's share, frame-coordinate indexing
 BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
 
 int blend_log_rows(); // rows of 64 records per wave in the blend log (stp_render_replay.hip: BLEND_LOG_ROWS of stp_blend.h)
@@ -147,7 +147,8 @@ struct FrameParams {
 struct BackwardParams {
     const float* pixel_colors;
     const float* dL_dpix;
-    float* grad_rec;    // P x 16: written by the render half, read by the per-Gaussian half
+    float* grad_rec;    // P x grad_stride: written by the render half, read by the per-Gaussian half
+    int grad_stride;    // STP_GRAD_RECORD_FLOATS, or STP_GRAD_RECORD_USED with phases bit 2 (compact records)
     float* dL_dmean2D;  // outputs of the per-Gaussian half from here on
     float* dL_dopacity;
     float* dL_dcolor;
@@ -160,12 +161,12 @@ struct BackwardParams {
 
 // ---- launchers (one per stage; each returns hipSuccess or the launch error) ----
 hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, uint32_t* tile_counts, hipStream_t st); // tile_counts: nullptr = do not count per tile
-hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int T, bool with_log, bool tile_counters, hipStream_t st); // status, ranges, tile flags (+ tile counters)
+hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int tile0, int n_tiles, bool with_log, bool tile_counters, hipStream_t st); // status, ranges, tile flags (+ tile counters) of the window's tiles
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st);
 hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st); // second level of the scan + the hand-over
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays; cap: slots of a run-ahead launch (0xFFFFFFFF = exact)
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, hipStream_t st);

@@ -436,7 +436,10 @@ struct DupArgs {
     uint64_t* keys;
     uint32_t* values;
     uint32_t* tile_cursor; // binning by tile counters: next free slot of every tile's segment (nullptr: slots by point_offsets)
+    uint32_t cap;          // slots the arrays hold: a run-ahead forward (stp_api.hip) launches on a capacity, not on num_rendered; 0xFFFFFFFF = exact
+    int n_gauss_blocks;    // workgroups that own Gaussians; the DUP_PAD_BLOCKS behind them fill [num_rendered, cap) with padding entries
 };
+constexpr int DUP_PAD_BLOCKS = 128;
 
 // key + write decision of ONE (Gaussian, tile) pair: reference duplicateWithKeys_extended, stopthepop_common.cuh:420-460
 struct DupGaussian { float2 xy; float4 co; float thr; float3 p0, p1, p2; float global_depth; };
@@ -463,6 +466,18 @@ __device__ __forceinline__ bool duplicate_tile(const DupArgs& a, const DupGaussi
 __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
 {
 #pragma clang fp contract(off)
+    if ((int)blockIdx.x >= a.n_gauss_blocks) {
+        // run-ahead forward: the sort and range passes behind this kernel run over `cap` slots; the slots behind the frame's true count (known
+        // on the device: the two-level scan's grand total) become padding entries, which sort behind every tile (an overflowing frame -- count
+        // above cap -- pads nothing, writes nothing out of bounds and is redone by the host with the exact size)
+        const int nb = a.n_gauss_blocks;
+        const uint32_t total = a.g.block_prefix[nb - 1] + a.g.block_sums[nb - 1];
+        for (uint64_t i = (uint64_t)total + ((uint32_t)blockIdx.x - (uint32_t)nb) * 256u + threadIdx.x; i < (uint64_t)a.cap; i += (uint64_t)DUP_PAD_BLOCKS * 256u) {
+            a.values[i] = 0xFFFFFFFFu;
+            a.keys[i] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
+        }
+        return;
+    }
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = idx < a.P && a.radii[idx] > 0;   // (no early return: the wave's lanes meet again for the large rectangles)
     const bool tbc = a.tile_based_culling != 0;
@@ -515,7 +530,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
                         const uint32_t slot = atomicAdd(&a.tile_cursor[(uint32_t)(key >> 32)], 1u);
                         a.values[slot] = (uint32_t)idx;
                         a.keys[slot] = key;
-                    } else if (off < off_to) {
+                    } else if (off < off_to && off < a.cap) {
                         a.values[off] = (uint32_t)idx;
                         a.keys[off] = key;
                     }
@@ -523,7 +538,7 @@ __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
                 }
             }
         if (!a.tile_cursor) // pad what the (slightly more generous) preprocess count reserved but culling did not use
-            for (; off < off_to; off++) { // (reference stopthepop_common.cuh:503-508, 614-619)
+            for (; off < off_to && off < a.cap; off++) { // (reference stopthepop_common.cuh:503-508, 614-619)
                 a.values[off] = 0xFFFFFFFFu;
                 a.keys[off] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
             }
@@ -552,10 +567,10 @@ __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
             const bool wr = t < n && duplicate_tile(a, s, cam, tbc, eval_max, per_tile_depth, sx0 + (t - ty * w), sy0 + ty, key);
             const unsigned long long wm = __ballot(wr);
             const uint32_t slot = base + (uint32_t)lanes_below(wm);
-            if (wr && slot < s_to) { a.values[slot] = s_idx; a.keys[slot] = key; }
+            if (wr && slot < s_to && slot < a.cap) { a.values[slot] = s_idx; a.keys[slot] = key; }
             base += (uint32_t)__popcll(wm);
         }
-        for (uint32_t p = base + (uint32_t)lane; p < s_to; p += 64u) {
+        for (uint32_t p = base + (uint32_t)lane; p < s_to && p < a.cap; p += 64u) {
             a.values[p] = 0xFFFFFFFFu;
             a.keys[p] = make_sort_key(INVALID_TILE_ID, FLT_MAX);
         }
@@ -605,7 +620,7 @@ hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* 
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, hipStream_t st)
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, hipStream_t st)
 {
     DupArgs a;
     a.P = f.P; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
@@ -613,7 +628,10 @@ hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const 
     a.inv_vp = f.inv_viewprojmatrix; a.cam = f.cam_pos; a.radii = radii; a.g = g;
     a.tile_cursor = tile_cursor;
     a.keys = tile_cursor ? b.keys : b.keys_unsorted; a.values = tile_cursor ? b.point_list : b.point_list_unsorted;
-    hipLaunchKernelGGL(duplicate_kernel, dim3((f.P + 255) / 256), dim3(256), 0, st, a);
+    const bool capped = cap != 0xFFFFFFFFu && g.block_prefix != nullptr && tile_cursor == nullptr; // (a capacity launch needs the count on the device)
+    a.cap = capped ? cap : 0xFFFFFFFFu;
+    a.n_gauss_blocks = (f.P + 255) / 256;
+    hipLaunchKernelGGL(duplicate_kernel, dim3(a.n_gauss_blocks + (capped ? DUP_PAD_BLOCKS : 0)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -687,22 +705,22 @@ hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, u
 // words, the tile ranges (reference rasterizer_impl.cu:354) and the tile flags (0 = "this tile's log is valid", all ones =
 // "the forward recorded no log", see carve_image).
 __global__ void __launch_bounds__(256) frame_init_kernel(uint32_t* __restrict__ status, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_flags,
-                                                          uint32_t flag_value, uint32_t* __restrict__ tile_counts, int T)
+                                                          uint32_t flag_value, uint32_t* __restrict__ tile_counts, int tile0, int T)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 64) status[i] = 0u;
-    if (i < T) {
-        ranges[i] = make_uint2(0u, 0u);
-        tile_flags[i] = flag_value;
-        if (tile_counts) tile_counts[i] = 0u;
+    if (i < T) { // the tiles of the frame's tile-row window (the arrays hold no others: carve_image)
+        ranges[tile0 + i] = make_uint2(0u, 0u);
+        tile_flags[tile0 + i] = flag_value;
+        if (tile_counts) tile_counts[tile0 + i] = 0u;
     }
 }
 
-hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int T, bool with_log, bool tile_counters, hipStream_t st)
+hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int tile0, int T, bool with_log, bool tile_counters, hipStream_t st)
 {
     const int n = T > 64 ? T : 64;
     hipLaunchKernelGGL(frame_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g.status, img.ranges, img.tile_flags, with_log ? 0u : 0xFFFFFFFFu,
-                       tile_counters ? img.tile_counts : nullptr, T);
+                       tile_counters ? img.tile_counts : nullptr, tile0, T);
     return hipGetLastError();
 }
 

@@ -4,9 +4,9 @@
 // three-level resort to rediscover the order in which every pixel blended its Gaussians.  MI355X has 288 GB of
 // HBM, so the training forward (render_hier_kernel<..., MODE_FWD_RECORD>, render_kbuffer_kernel<WIN, KB_FWD_RECORD>)
 // simply writes that order down -- 2 bytes (the tile-list position) per blended (pixel, Gaussian) pair,
-// BLEND_LOG_DEPTH = 256 records per pixel, 512 B per pixel, 1.07 GB at 1080p -- and this kernel walks each pixel's log
+// BLEND_LOG_DEPTH = 192 records per pixel (+ one spare row: 386 B per pixel, 0.80 GB at 1080p) -- and this kernel walks each pixel's log
 // front to back.  The gradient maths per pair is the reference's (blend_backward_terms); the result is the same sum
-// in a different order.  Tiles whose log overflowed (a pixel with more than 256 blended entries, a list longer than
+// in a different order.  Tiles whose log overflowed (a pixel with more than BLEND_LOG_DEPTH blended entries, a list longer than
 // 65535) are flagged by the forward and left to the re-sorting backward kernels, which then run only on those tiles.
 //
 // Layout: one 256-thread workgroup per tile, thread -> pixel mapping identical to the forward (wave = row of four
@@ -60,6 +60,23 @@ namespace {
 #endif
 #ifndef STP_REPLAY_WINDOW
 #define STP_REPLAY_WINDOW 512
+#endif
+#ifndef STP_REPLAY_RAWADD
+#define STP_REPLAY_RAWADD 0 // (MEASURED, round 4, off) The fixed-point conversion is fma(g, scale, 1.5 * 2^52): the double's low mantissa bits then hold round(g * scale) in two's
+                            // complement, and rounds 1-3 subtracted the bit pattern of 1.5 * 2^52 before the LDS add -- a 64-bit integer subtraction,
+                            // two half-rate VALU instructions per term, eighteen per blend.  1: the RAW bits are added.  Every add then carries the
+                            // constant 0x4338 << 48 along, which only ever touches the sum's top 16 bits: with |sum| < 2^47 the low 48 bits ARE the
+                            // sum in two's complement, and the flush sign-extends them (it never needs to know how many adds a slot received).
+                            // The price is range: |q| < 2^39 per add (256 pixels per tile), so the scale is 2^27 / M instead of 2^31 / M and a term
+                            // of 2^11 M or more takes the global-atomic path (2^20 M before); resolution 7.5e-9 M per add.
+                            // MEASURED (one box, alternating, profiles/r04_replay_rawadd_ab.txt): 18 of a step's ~125 VALU instructions gone
+                            // (isa_cost: 517 -> 437 SIMD cycles) and C2-full replay 0.856 against 0.859 ms -- nothing; C3 1.645 against 1.561 and
+                            // C5 1.629 against 1.530 ms -- WORSE, their larger terms now miss the cap and go to global atomics.  The kernel
+                            // is not bound by its VALU stream.
+#endif
+#ifndef STP_REPLAY_ABLATE
+#define STP_REPLAY_ABLATE 0 // timing experiments (results are WRONG): 1 = no LDS adds (conversions kept), 2 = no DPP merge levels, 3 = every entry
+                            // record read from list position 0 (no gather), 4 = 1 + 3
 #endif
 #ifndef STP_REPLAY_FASTEXP
 #define STP_REPLAY_FASTEXP 1 // the Gaussian weight of a replayed blend with a plain v_exp_f32 (see blend_terms)
@@ -137,7 +154,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     int md_exp = 0;
     const bool md_ok = md > 0.0f && md < 3.0e38f;
     if (md_ok) (void)frexpf(md, &md_exp);
-    const double fx_scale = ldexp(1.0, 31 - md_exp), fx_inv = ldexp(1.0, md_exp - 31);
+    constexpr int FX_BITS = STP_REPLAY_RAWADD ? 27 : 31, FX_CAP_BITS = STP_REPLAY_RAWADD ? 11 : 20;
+    const double fx_scale = ldexp(1.0, FX_BITS - md_exp), fx_inv = ldexp(1.0, md_exp - FX_BITS);
     // factor of term k that the blend step leaves out (STP_REPLAY_FOLD): applied once per sum
     auto term_scale = [&](int k) __attribute__((always_inline)) -> float {
 #if STP_REPLAY_FOLD && STP_REPLAY_STRAIGHT
@@ -147,7 +165,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 #endif
     };
     const double fx_inv_term = fx_inv * (double)term_scale(lane & 15); // (flush: lane & 15 is the term a lane writes back)
-    const float fx_cap = (md_ok || md == 0.0f) ? ldexpf(1.0f, min(md_exp + 20, 126)) : 0.0f; // (a tile whose M is not finite: nothing fits, every term goes to memory)
+    const float fx_cap = (md_ok || md == 0.0f) ? ldexpf(1.0f, min(md_exp + FX_CAP_BITS, 126)) : 0.0f; // (a tile whose M is not finite: nothing fits, every term goes to memory)
     // Colour terms: |alpha T dL/dpixel| < M = 2^md_exp by construction (M >= max |dL/dpixel| of the tile), and a lane that the
     // DPP merge has loaded with its partners' terms carries at most 16 of them: round(t 2^22 / M) fits 27 bits, the sum over
     // the tile's 256 pixels 31 -- 32-bit LDS adds, which cost half of the 64-bit ones, also where lanes share an address
@@ -180,7 +198,11 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
 
     const uint32_t list_last = (uint32_t)(list_len - 1);
     auto entry_at_clamped = [&](uint32_t p) __attribute__((always_inline)) { // (p beyond the list -- a corrupt log word -- reads the last entry)
+#if STP_REPLAY_ABLATE == 3 || STP_REPLAY_ABLATE == 4
+        const uint32_t off = min(p, 0u) << 4;
+#else
         const uint32_t off = min(p, list_last) << 4;
+#endif
         auto at = [&](const float4* base) __attribute__((always_inline)) { return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + off); };
         return Entry{at(eC), at(eD), at(eF)};
     };
@@ -279,8 +301,9 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     // merge lanes on the same position, then add to the window's sums (lo = first position of the window)
     // deep (wave-uniform): also the two mirror levels inside the 16-lane row
     // one_window (a literal at both call sites): the list fits the window -- no position lies in front of it, a position IS its slot
+    unsigned long long ablate_sink = 0ull;
     auto merge_and_add = [&](bool ok, int cur_pos, int cur_id, float (&g)[9], int lo, const bool deep, const bool one_window) __attribute__((always_inline)) {
-#if STP_REPLAY_PAIRMERGE
+#if STP_REPLAY_PAIRMERGE && STP_REPLAY_ABLATE != 2
         // Pairwise merge (DPP): a lane and its partner -- lane^1, lane^2, then the mirror lanes of its 8-lane half and
         // row -- that hold the same list position sum their terms in registers and only one of them goes to LDS.  Per
         // step 55 lanes blend on 17.5 distinct positions (C2); the LDS atomics serialise on equal addresses and were the
@@ -346,8 +369,16 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 for (int kk = ACC64_FIRST; kk < 9; kk++) {
                     // round-to-nearest integer of g*scale through the 1.5*2^52 trick (|g*scale| < 2^51 + margin)
                     const double tq = fma((double)g[kk], fx_scale, 6755399441055744.0);
+#if STP_REPLAY_RAWADD
+                    atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + slot], (unsigned long long)__double_as_longlong(tq));
+#else
                     const long long qv = __double_as_longlong(tq) - 0x4338000000000000ll;
+#if STP_REPLAY_ABLATE == 1 || STP_REPLAY_ABLATE == 4
+                    ablate_sink ^= (unsigned long long)qv + (unsigned long long)slot;
+#else
                     atomicAdd(&s_acc[acc_copy + (kk - ACC64_FIRST) * WINDOW + slot], (unsigned long long)qv);
+#endif
+#endif
                 }
             } else { // a record the re-sort moved across a window boundary, or a term too large for the fixed point
 #endif
@@ -383,6 +414,12 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
                 }
 #endif
                 long long v = (long long)s_acc[(term - ACC64_FIRST) * WINDOW + p];
+#if STP_REPLAY_RAWADD
+                static_assert(STP_REPLAY_COPIES == 1, "the raw-bits sums are decoded per slot");
+                if (v != 0) { s_acc[(term - ACC64_FIRST) * WINDOW + p] = 0ull; v = (long long)((unsigned long long)v << 16) >> 16; } // the low 48 bits, sign-extended
+                if (v != 0) atomicAdd(grad_slot(a, __float_as_int(eC[pp].w), term), (float)((double)v * fx_inv_term));
+                continue;
+#endif
                 if (STP_REPLAY_COPIES == 2) { v += (long long)s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p]; s_acc[9 * WINDOW + (term - ACC64_FIRST) * WINDOW + p] = 0ull; }
                 if (v != 0) {
                     s_acc[(term - ACC64_FIRST) * WINDOW + p] = 0ull;
@@ -455,14 +492,13 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         auto one_step = [&](const int k, const Entry& cur, Entry& nxt) __attribute__((always_inline)) {
             const int kr = k - off; // my record index
             // (index checks as one unsigned compare each -- n >= 0; the entry offset clamped with one unsigned minimum; the log row of a
-            // record index outside 0 .. 255 wraps to some other row of my slice, whose word is read and never used)
+            // record index outside the log is clamped to the last row of my slice -- the spare row --, whose word is read and never used)
             const bool have = (uint32_t)kr < (uint32_t)n;
             const bool have1 = (uint32_t)(kr + 1) < (uint32_t)n;
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             const int pos1 = have1 ? raw1 : -1;
             nxt = entry_at_clamped(have1 ? (uint32_t)raw1 : 0u);
-            static_assert((BLEND_LOG_DEPTH & (BLEND_LOG_DEPTH - 1)) == 0, "log rows are addressed modulo the depth");
-            raw1 = log_at((uint32_t)(kr + 2) & (uint32_t)(BLEND_LOG_DEPTH - 1));
+            raw1 = log_at(min((uint32_t)(kr + 2), (uint32_t)(BLEND_LOG_ROWS - 1)));
             pos = pos1;
 #if !STP_REPLAY_HOIST && !STP_REPLAY_STRAIGHT
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
@@ -486,6 +522,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         }
 #endif
         flush_range(0, list_len);
+        if (ablate_sink == 0x123456789abcull) a.grad_rec[0] = 1.0f; // (STP_REPLAY_ABLATE: keeps the conversions alive)
     } else {
     // ---- longer lists, window by window: every lane pauses at its first record beyond the window ----
     int k = 0; // records consumed by this lane

@@ -488,7 +488,7 @@ hipError_t launch_render_backward(const FrameParams& f, const GeometryState& g, 
                                   const BackwardParams& bw, hipStream_t st, std::string* err)
 {
     RenderArgs a = make_args(f, g, b, img);
-    a.pixel_colors = bw.pixel_colors; a.dL_dpix = bw.dL_dpix; a.grad_rec = bw.grad_rec;
+    a.pixel_colors = bw.pixel_colors; a.dL_dpix = bw.dL_dpix; a.grad_rec = bw.grad_rec; a.grad_stride = bw.grad_stride;
     const dim3 grid(f.gx * (f.ty1 - f.ty0)), block(BLOCK);
     if (grid.x == 0) return hipSuccess;
     switch (f.s.sort_mode) {

@@ -34,6 +34,7 @@ struct TileSortArgs {
     const float* features;
     int id_passes;            // long segments: counting passes on the id bytes before the depth passes (0: already in id order)
     int gx;                   // tiles per row
+    int tile0;                // first tile of the frame's tile-row window (the grid covers the window's tiles)
     int cull_mask;            // leave every entry's 16-bit sub-tile mask in entF.w (see write_entry): 1 = hierarchical mode's 4x4 culling, 2 = the k-buffer kernel's sub-tile pre-test
     float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
 };
@@ -99,7 +100,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
     // a contiguous run of tiles and the 64-byte lines of the Gaussians that neighbouring tiles share hit in that XCD's L2
     const int n_wg = (int)gridDim.x, wg = (int)blockIdx.x;
     const int xq = n_wg >> 3, xr = n_wg & 7, xcd = wg & 7;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
+    const int tile = a.tile0 + (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n <= MIN_N || (CAP == TS_SMALL && n > TS_SMALL)) return; // empty, or the other instantiation's tile
@@ -211,10 +212,13 @@ hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g,
     a.gpack = entries ? g.gpack : nullptr;
     a.features = f.colors_precomp ? f.colors_precomp : g.rgb;
     a.gx = f.gx;
+    a.tile0 = f.gx * f.ty0;
     a.cull_mask = subtile_mask_kind(f.s);
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
-    hipLaunchKernelGGL((tile_sort_gather_kernel<TS_SMALL, 0>), dim3(f.gx * f.gy), dim3(256), 0, st, a);
-    hipLaunchKernelGGL((tile_sort_gather_kernel<TS_CAP, TS_SMALL>), dim3(f.gx * f.gy), dim3(256), 0, st, a);
+    const int n_tiles = f.gx * (f.ty1 - f.ty0);
+    if (n_tiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL((tile_sort_gather_kernel<TS_SMALL, 0>), dim3(n_tiles), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((tile_sort_gather_kernel<TS_CAP, TS_SMALL>), dim3(n_tiles), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -86,7 +86,9 @@ def _load():
     L.stp_timing_read.restype = ci
     L.stp_timing_text.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.stp_timing_text.restype = ctypes.c_size_t
-    if L.stp_abi_version() != 5:
+    L.stp_binning_layout_count.argtypes = [vp, ci]
+    L.stp_binning_layout_count.restype = ci
+    if L.stp_abi_version() != 6:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L
     return L
@@ -172,9 +174,15 @@ def backward_mode() -> str:
     return _backward_mode
 
 
-def blend_log_bytes(width: int, height: int) -> int:
-    """Bytes of the blend log of one forward at this resolution (514 B per pixel of the 16x16 tile grid; the library's own figure)."""
-    return int(_load().stp_blend_log_bytes(int(width), int(height)))
+def blend_log_bytes(width: int, height: int, tile_rows=None) -> int:
+    """Bytes of the blend log of one forward at this resolution (386 B per pixel of the 16x16 tile grid; the library's own figure).
+    tile_rows = (y0, y1): of a forward restricted to that tile-row window (a rank of a tile-row shard holds its rows' log only)."""
+    L = _load()
+    if tile_rows is None:
+        return int(L.stp_blend_log_bytes(int(width), int(height)))
+    L.stp_blend_log_bytes_rows.argtypes = [ctypes.c_int] * 4
+    L.stp_blend_log_bytes_rows.restype = ctypes.c_size_t
+    return int(L.stp_blend_log_bytes_rows(int(width), int(height), int(tile_rows[0]), int(tile_rows[1])))
 
 
 class LogLease:
@@ -197,7 +205,7 @@ def live_log_bytes(device=None) -> int:
     return _log_live.get(_device_index(device), 0)
 
 
-def decide_recording(mode, device, width: int, height: int) -> bool:
+def decide_recording(mode, device, width: int, height: int, tile_rows=None) -> bool:
     """Does a training forward on `device` record the blend log under policy `mode` (None = the process default)?"""
     mode = mode or _backward_mode
     if mode not in _BACKWARD_MODES:
@@ -205,7 +213,7 @@ def decide_recording(mode, device, width: int, height: int) -> bool:
     if mode != "auto":
         return mode == "replay"
     idx = _device_index(device)
-    need = blend_log_bytes(width, height)
+    need = blend_log_bytes(width, height, tile_rows)
     pooled = list(_native().pooled_sizes(idx))
     reuse = any(need <= n for n in pooled)   # a pooled buffer takes the new log: no new memory
     return _log_live.get(idx, 0) + sum(pooled) + (0 if reuse else need) <= _log_budget_bytes
@@ -290,12 +298,13 @@ def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, 
 
     Extension for tile-row sharding (not in the reference): phases=1 runs only the render half and
     returns its per-Gaussian partial sums as the library's (P,16) gradient records (stp_raster.h);
-    phases=2 takes the records (after the caller's all-reduce) as `partial` and runs the preprocess half."""
+    phases=2 takes the records (after the caller's all-reduce) as `partial` and runs the preprocess half.
+    Adding 4 to either selects COMPACT records, (P,9) with no padding: the tensor that is all-reduced as it is."""
     out = (_host or _native()).rasterize_gaussians_backward(
         background, means3D, radii, opacities, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
         inv_viewprojmatrix, tan_fovx, tan_fovy, pixel_colors, dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer,
         imageBuffer, settings_dict, bool(debug), _records_log(settings_dict), int(phases), partial)
-    return out[0] if phases == 1 else tuple(out)
+    return out[0] if (int(phases) & 3) == 1 else tuple(out)
 
 
 def mark_visible(means3D, viewmatrix, projmatrix) -> torch.Tensor:
@@ -335,17 +344,45 @@ def geometry_array(geomBuffer, P, settings_dict, name):
 
 
 def binning_array(binningBuffer, R, name):
+    """Named view of the first R entries of a sub-array.  (A run-ahead forward carves the buffer for the capacity it guessed, not for
+    num_rendered: the library remembers which, stp_binning_layout_count.)"""
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
-    if _load().stp_binning_layout(int(R), name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
+    L = _load()
+    lay = int(L.stp_binning_layout_count(ctypes.c_void_p(binningBuffer.data_ptr()), int(R))) if int(R) > 0 else 0
+    if L.stp_binning_layout(lay, name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
         raise KeyError(name)
-    return _view(binningBuffer, off.value, cnt.value, _BIN_TYPES[name])
+    n = cnt.value // lay * int(R) if lay > 0 else cnt.value
+    return _view(binningBuffer, off.value, n, _BIN_TYPES[name])
 
 
-def image_array(imgBuffer, W, H, name):
+def image_array(imgBuffer, W, H, name, tile_rows=None):
+    """Named view into an image buffer.  tile_rows = (y0, y1): the buffer of a forward restricted to that tile-row window -- it holds the
+    window's pixel rows / tiles only (element 0 = the window's first pixel / tile)."""
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
-    if _load().stp_image_layout(int(W), int(H), name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
+    L = _load()
+    L.stp_image_layout_rows.argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    y0, y1 = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+    if L.stp_image_layout_rows(int(W), int(H), y0, y1, name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
         raise KeyError(name)
     return _view(imgBuffer, off.value, cnt.value, _IMG_TYPES[name])
+
+
+def set_run_ahead(flag: bool) -> bool:
+    """Run-ahead forward on / off (include/stp_raster.h: stp_set_run_ahead); returns the previous setting.  Off by default."""
+    L = _load()
+    L.stp_set_run_ahead.argtypes = [ctypes.c_int]
+    L.stp_set_run_ahead.restype = None
+    L.stp_get_run_ahead.restype = ctypes.c_int
+    prev = bool(L.stp_get_run_ahead())
+    L.stp_set_run_ahead(int(bool(flag)))
+    return prev
+
+
+def reset_size_guesses() -> None:
+    """The next forward of every kind runs without a size guess (hand-over in the middle of the frame, exact binning request) -- tests."""
+    L = _load()
+    L.stp_reset_size_guesses.restype = None
+    L.stp_reset_size_guesses()
 
 
 def timing_enable(flag: bool) -> None:

@@ -178,15 +178,17 @@ class _ShardedRasterize(torch.autograd.Function):
         sdict = dict(rs.settings.to_dict())
         y0, y1 = parts[rank]
         n_rows = tile_rows(rs.image_height)
-        sdict["_tile_rows"] = (y0, y1) if y1 > y0 else (n_rows, n_rows)   # (an empty block; (0, 0) would mean "all rows" to the library)
+        rows = (y0, y1) if y1 > y0 else (n_rows, n_rows)   # (an empty block; (0, 0) would mean "all rows" to the library)
+        sdict["_tile_rows"] = rows
         ctx.log_lease = None
         if any(ctx.needs_input_grad) and not rs.render_depth:   # the backward-mode policy of the unsharded autograd function (__init__.py)
             uses_log = int(sdict["sort_settings"]["sort_mode"]) in (2, 3)
             if uses_log and means3D.is_cuda and means3D.size(0) != 0 and \
-                    _C.decide_recording(sdict.get("_backward_mode"), means3D.device, rs.image_width, rs.image_height):
+                    _C.decide_recording(sdict.get("_backward_mode"), means3D.device, rs.image_width, rs.image_height, rows):
                 sdict["_record_blend_log"] = True
                 sdict["_backward_mode"] = "replay"
-                ctx.log_lease = _C.LogLease(_C._device_index(means3D.device), _C.blend_log_bytes(rs.image_width, rs.image_height))
+                # (the image buffer and the blend log of a rank cover ITS tile rows only: 1 / world of the frame's log)
+                ctx.log_lease = _C.LogLease(_C._device_index(means3D.device), _C.blend_log_bytes(rs.image_width, rs.image_height, rows))
             else:
                 sdict["_backward_mode"] = "resort"
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
@@ -203,8 +205,11 @@ class _ShardedRasterize(torch.autograd.Function):
             # pool, and another rasterizer on the device (an eval render, a second sharded module) may have reused it by the
             # time the next frame is partitioned -- only the small per-row tensor is kept
             gx = (rs.image_width + 15) // 16
-            r = _C.image_array(imgBuffer, rs.image_width, rs.image_height, "ranges").reshape(-1, 2)[: gx * n_rows].to(torch.int64)
-            shard_state["pending"] = (r[:, 1] - r[:, 0]).reshape(n_rows, gx).sum(dim=1).to(torch.float32)
+            # (the buffer holds the ranges of this rank's rows only; the other rows of the per-row vector stay zero and come from their owners)
+            r = _C.image_array(imgBuffer, rs.image_width, rs.image_height, "ranges", tile_rows=rows).reshape(-1, 2)[: gx * (rows[1] - rows[0])].to(torch.int64)
+            pending = torch.zeros(n_rows, dtype=torch.float32, device=r.device)
+            pending[rows[0]:rows[1]] = (r[:, 1] - r[:, 0]).reshape(rows[1] - rows[0], gx).sum(dim=1).to(torch.float32)
+            shard_state["pending"] = pending
         full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
         ctx.mark_non_differentiable(radii)
         # every rank returns a (3,H,W) tensor: the assembled frame where it is available, else the local strip image
@@ -221,18 +226,17 @@ class _ShardedRasterize(torch.autograd.Function):
         args = (rs.bg, means3D, radii, opacities, colors_precomp, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, color, grad_out_color, sh,
                 rs.sh_degree, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, sdict, rs.debug)
-        records = _C.rasterize_gaussians_backward(*args, phases=1)
-        # sum over ranks.  Only 9 of a record's 16 floats carry data (the padding buys single-request atomics on
-        # chip, it should not cross xGMI): 36 instead of 64 bytes per Gaussian on the wire.
-        used = records[:, :RECORD_USED].contiguous()
-        if _host_staged(dist) and used.is_cuda:
-            host = used.cpu()
+        # The render half writes COMPACT records -- (P, 9) floats, no padding (phases bit 2, include/stp_raster.h) -- and that tensor is summed
+        # over the ranks AS IT IS: 36 bytes per Gaussian on the wire, no pack / unpack pass on either side (rounds 1-3 sliced the used
+        # columns out of the padded (P, 16) records and copied them back: two strided 36 MB copies per step at C2).
+        records = _C.rasterize_gaussians_backward(*args, phases=1 | 4)
+        if _host_staged(dist) and records.is_cuda:
+            host = records.cpu()
             dist.all_reduce(host)
-            used = host.to(records.device)
+            records = host.to(records.device)
         else:
-            dist.all_reduce(used)
-        records[:, :RECORD_USED] = used
-        out = _C.rasterize_gaussians_backward(*args, phases=2, partial=records)
+            dist.all_reduce(records)
+        out = _C.rasterize_gaussians_backward(*args, phases=2 | 4, partial=records)
         _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)
         if ctx.log_lease is not None:
             ctx.log_lease.release()

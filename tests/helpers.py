@@ -40,8 +40,13 @@ class GpuRun:
     """Runs one scene through the product's public API on cuda:0 and keeps what the tests inspect."""
 
     def __init__(self, scene, sdict, backward=True, device="cuda:0", tile_rows=None, debug=False, render_depth=False,
-                 cov3D_precomp=None, prefiltered=False):
-        """cov3D_precomp: (P,6) array -> passed INSTEAD of scales/rotations (ref: __init__.py:286-289 allows exactly one)."""
+                 cov3D_precomp=None, prefiltered=False, warm=True, run_ahead=None):
+        """cov3D_precomp: (P,6) array -> passed INSTEAD of scales/rotations (ref: __init__.py:286-289 allows exactly one).
+        warm: the frame is rendered TWICE.  The library's default forward takes the reference's path -- hand-over of num_rendered in the
+        middle of the frame, exact binning size; with run-ahead switched on (_C.set_run_ahead) every forward but the first of its kind is
+        launched as a whole on a capacity guessed from the frames before (stp_api.hip).  The untracked first pass runs the default path,
+        the second -- the one the tests inspect -- the run-ahead path; both must return the same image, radii and count, bit for bit.
+        run_ahead (with warm=False): run this one frame with the switch set like this."""
         import torch
         import diff_gaussian_rasterization as dgr
         from diff_gaussian_rasterization import _C
@@ -67,14 +72,45 @@ class GpuRun:
             prefiltered=prefiltered, settings=es, render_depth=render_depth, debug=debug)
         self.rs = rs
         rast = dgr.GaussianRasterizer(rs)
+        self.exact_pass = None
+        self.run_ahead_before = None
+        if warm and not debug:
+            _C.reset_size_guesses()
+            self.run_ahead_before = _C.set_run_ahead(False)
+            empty_ = torch.Tensor([])
+            e_ = lambda x: empty_ if x is None else x.detach()
+            o = _C.rasterize_gaussians(rs.bg, self.means3D.detach(), e_(self.colors), self.opac.detach(), e_(self.scales), e_(self.rots),
+                                       rs.scale_modifier, e_(self.cov3D), rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx,
+                                       rs.tanfovy, rs.image_height, rs.image_width, e_(self.shs), rs.sh_degree, rs.campos, prefiltered,
+                                       es.to_dict(), render_depth, debug)
+            self.exact_pass = (int(o[0]), o[1].clone(), o[2].clone())
+            _C.release_scratch(o[5]); _C.release_scratch(o[4])
+            del o
+            _C.set_run_ahead(True)
+        elif run_ahead is not None:
+            self.run_ahead_before = _C.set_run_ahead(bool(run_ahead))
+        try:
+            self._run(rast, rs, es, backward, dev, prefiltered, render_depth, debug)
+        finally:
+            if self.run_ahead_before is not None:
+                _C.set_run_ahead(self.run_ahead_before)
+
+    def _run(self, rast, rs, es, backward, dev, prefiltered, render_depth, debug):
+        import torch
+        from diff_gaussian_rasterization import _C
+        scene = self.scene
         color, radii = rast(self.means3D, self.means2D, self.opac, shs=self.shs, colors_precomp=self.colors,
                             scales=self.scales, rotations=self.rots, cov3D_precomp=self.cov3D)
         self.color_t = color
         self.color = color.detach().cpu().numpy()
         self.radii = radii.cpu().numpy()
+        if self.exact_pass is not None:   # exact path == run-ahead path, bit for bit (NaN == NaN: render_depth of an empty frame)
+            assert torch.equal(torch.nan_to_num(self.exact_pass[1], nan=-1.0), torch.nan_to_num(color.detach(), nan=-1.0)), "run-ahead forward differs from the exact one"
+            assert torch.equal(self.exact_pass[2], radii)
         fn = color.grad_fn
         if fn is not None:
             self.num_rendered = fn.num_rendered
+            assert self.exact_pass is None or self.exact_pass[0] == self.num_rendered
             saved = fn.saved_tensors
             self.geom, self.binning, self.img = saved[9], saved[10], saved[11]
         else:  # forward-only run (no tensor requires grad): fetch the scratch buffers with a direct _C call
