@@ -680,7 +680,9 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // L = entries the device-wide passes run over: num_rendered, or the capacity of a run-ahead launch (dup_cap = the same value then)
     bool colour_started = !(side && colour_late);
     auto binning_and_render = [&](const GeometryState& gd, const BinningState& b, int L, uint32_t dup_cap) -> int {
-        STP_TRY(launch_duplicate(f, gd, radii, b, atomic_bin ? img.tile_cursor : nullptr, dup_cap, st), "duplicate launch");
+        uint32_t* zero_ptr = nullptr; size_t zero_words = 0; // (the tile-bit sort's histograms / look-back states / block counters: cleared here, once)
+        if (!atomic_bin && tile_local_sort) sort_zero_region(b, (size_t)L, &zero_ptr, &zero_words);
+        STP_TRY(launch_duplicate(f, gd, radii, b, atomic_bin ? img.tile_cursor : nullptr, dup_cap, zero_ptr, zero_words, st), "duplicate launch");
         STP_DEBUG_SYNC("duplicate");
         g_timer.mark(2, st);
         if (!colour_started) {
@@ -691,7 +693,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         if (atomic_bin) {
             STP_TRY(launch_bin_pad(b, img, L, st), "pad entries");
         } else {
-            STP_TRY(launch_sort(f, b, L, tile_local_sort, st), "radix sort");
+            STP_TRY(launch_sort(f, b, L, tile_local_sort, zero_words != 0, st), "radix sort");
             STP_DEBUG_SYNC("sort");
             STP_TRY(launch_ranges(f, b, img, L, st), "tile ranges");
             STP_DEBUG_SYNC("ranges");

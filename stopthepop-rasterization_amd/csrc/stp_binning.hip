@@ -4,6 +4,7 @@
 // cub::DeviceRadixSort::SortPairs on key bits [0, 32+bit) (rasterizer_impl.cu:211-214,344-352) with
 // rocPRIM's device-wide primitives (both are stable LSD radix sorts, so the sorted list is the
 // same list).
+#include <cstdlib>
 #include <cstring> // rocPRIM 7.2's texture_cache_iterator.hpp uses unqualified memset
 #include <rocprim/rocprim.hpp>
 
@@ -30,12 +31,97 @@ size_t scan_temp_bytes(size_t P)
     return bytes;
 }
 
+// ---- the tile-bit sort: rocPRIM's onesweep kernels under our own driver ---------------------------------------------------------------
+// rocprim::radix_sort_pairs on the 13 tile bits is two onesweep passes (80 us at C2) -- and, per call, FIVE hipMemsetAsync of a few KB
+// (the digit histogram; per pass the look-back states and the ordered-block-id counter), each a launch-bound __amd_rocclr_fillBufferAligned
+// of 8 us on the GPU: 41 us per frame for nothing (profiles/r03_full/kernel_stats.csv: 5.1 fills per frame).  The library's host function
+// cannot be told to leave them out, but its device code is all in headers: the three kernels below are rocPRIM's own device functions
+// (onesweep_histograms / onesweep_scan_histograms / onesweep_iteration, its gfx950 tuning parameters, its look-back states), launched by
+// launch_sort() with every pass owning its OWN look-back states and block counter, so that all of them are zeroed ONCE -- by trailing
+// workgroups of duplicate_kernel, which runs in front of the sort anyway (BinningState::sort_zero).  Same passes, same stable order,
+// same sorted list bit for bit (STP_TILE_SORT=rocprim keeps the library call for comparison).
+namespace {
+namespace rpd = rocprim::detail;
+using OsConfig = rpd::wrapped_radix_sort_onesweep_config<rocprim::default_config, uint64_t, uint32_t>;
+constexpr rpd::radix_sort_onesweep_config_params OS = OsConfig::architecture_config<rpd::target_arch::gfx950>::params;
+constexpr unsigned OS_RADIX = 1u << OS.radix_bits_per_place;
+constexpr unsigned OS_HIST_ITEMS = OS.histogram.block_size * OS.histogram.items_per_thread;
+constexpr unsigned OS_SORT_ITEMS = OS.sort.block_size * OS.sort.items_per_thread;
+constexpr unsigned OS_MAX_PLACES = 4; // 32 tile bits at most
+using OsBlockId = rpd::block_id_wrapper<unsigned int, true>;
+
+struct OsLayout { // inside BinningState::sort_temp
+    uint32_t* offsets;                                  // [places][radix] digit histograms -> exclusive offsets   } zeroed once per frame
+    rpd::onesweep_lookback_state* lookback;             // [places][radix * blocks]                                   } (sort_zero)
+    unsigned int* block_ids;                            // [places]                                                   }
+    uint32_t* offsets_tmp;                              // [radix] (next-batch offsets: written, never read with one batch)
+    uint64_t* keys_tmp;                                 // [R]
+    uint32_t* values_tmp;                               // [R]
+    size_t zero_bytes, total;
+    uint32_t sort_blocks;
+};
+OsLayout os_layout(char* base, size_t R)
+{
+    OsLayout L{};
+    auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    L.sort_blocks = (uint32_t)((R + OS_SORT_ITEMS - 1) / OS_SORT_ITEMS);
+    size_t off = 0;
+    L.offsets = reinterpret_cast<uint32_t*>(base + off); off += up(sizeof(uint32_t) * OS_MAX_PLACES * OS_RADIX);
+    L.lookback = reinterpret_cast<rpd::onesweep_lookback_state*>(base + off); off += up(sizeof(rpd::onesweep_lookback_state) * OS_MAX_PLACES * OS_RADIX * (size_t)L.sort_blocks);
+    L.block_ids = reinterpret_cast<unsigned int*>(base + off); off += up(sizeof(unsigned int) * OS_MAX_PLACES);
+    L.zero_bytes = off;
+    L.offsets_tmp = reinterpret_cast<uint32_t*>(base + off); off += up(sizeof(uint32_t) * OS_RADIX);
+    L.keys_tmp = reinterpret_cast<uint64_t*>(base + off); off += up(sizeof(uint64_t) * R);
+    L.values_tmp = reinterpret_cast<uint32_t*>(base + off); off += up(sizeof(uint32_t) * R);
+    L.total = off;
+    return L;
+}
+
+__global__ void __launch_bounds__(OS.histogram.block_size) os_histograms_kernel(const uint64_t* keys, uint32_t* counts, uint32_t size, uint32_t full_blocks, unsigned begin_bit, unsigned end_bit)
+{
+    rpd::onesweep_histograms<OS.histogram.block_size, OS.histogram.items_per_thread, OS.radix_bits_per_place, false>(
+        keys, counts, size, full_blocks, rocprim::identity_decomposer{}, begin_bit, end_bit);
+}
+__global__ void __launch_bounds__(OS.histogram.block_size) os_scan_histograms_kernel(uint32_t* offsets)
+{
+    rpd::onesweep_scan_histograms<OS.histogram.block_size, OS.radix_bits_per_place>(offsets);
+}
+__global__ void __launch_bounds__(OS.sort.block_size) os_iteration_kernel(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* values_in, uint32_t* values_out, unsigned size,
+                                                                         uint32_t* offsets_in, uint32_t* offsets_out, rpd::onesweep_lookback_state* lookback, unsigned bit,
+                                                                         unsigned radix_bits, unsigned full_blocks, OsBlockId ordered_bid)
+{
+    rpd::onesweep_iteration<OS.sort.block_size, OS.sort.items_per_thread, OS.radix_bits_per_place, false, OS.radix_rank_algorithm>(
+        keys_in, keys_out, values_in, values_out, size, offsets_in, offsets_out, lookback, rocprim::identity_decomposer{}, bit, radix_bits, full_blocks, ordered_bid);
+}
+
+// (below OWN_MIN entries the library sorts with ONE workgroup-sort kernel: nothing to gain from four launches of our own)
+constexpr uint32_t OWN_MIN = 1u << 16, OWN_MAX = 1u << 30;
+bool own_onesweep_driver(size_t R)
+{
+    static const char* const env = std::getenv("STP_TILE_SORT");
+    static const bool lib = env && std::strcmp(env, "rocprim") == 0;
+    static const bool always = env && std::strcmp(env, "own") == 0; // (tests: also below OWN_MIN)
+    return !lib && (R >= OWN_MIN || (always && R > 0)) && R < OWN_MAX;
+}
+} // namespace
+
 size_t sort_temp_bytes(size_t R)
 {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                     R, 0u, 64u);
-    return bytes;
+    const size_t own = os_layout(nullptr, R).total;
+    return bytes > own ? bytes : own;
+}
+
+// what duplicate_kernel's trailing workgroups clear in front of the tile-bit sort (nothing with the library's own driver)
+void sort_zero_region(const BinningState& b, size_t R, uint32_t** ptr, size_t* words)
+{
+    *ptr = nullptr; *words = 0;
+    if (!own_onesweep_driver(R)) return;
+    const OsLayout L = os_layout(b.sort_temp, R);
+    *ptr = reinterpret_cast<uint32_t*>(b.sort_temp);
+    *words = L.zero_bytes / sizeof(uint32_t);
 }
 
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st)
@@ -46,13 +132,39 @@ hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t
 
 // tile_bits_only: sort on the tile bits alone (two radix passes; the depth order inside every tile's segment is then
 // established by launch_tile_sort_gather, stp_tilesort.hip); otherwise the reference's full sort on bits [0, 32 + bit).
-hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, hipStream_t st)
+// zeroed: duplicate_kernel has cleared sort_zero_region() for this R (the own driver's precondition)
+hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, bool zeroed, hipStream_t st)
 {
     if (R <= 0) return hipSuccess;
     const uint32_t bit = higher_msb((uint32_t)(f.gx * f.gy));
-    size_t bytes = b.sort_temp_bytes;
-    return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted, b.point_list, (size_t)R,
-                                     tile_bits_only ? 32u : 0u, 32u + bit, st);
+    if (!(tile_bits_only && zeroed && own_onesweep_driver((size_t)R))) {
+        size_t bytes = b.sort_temp_bytes;
+        return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted, b.point_list, (size_t)R,
+                                         tile_bits_only ? 32u : 0u, 32u + bit, st);
+    }
+    const OsLayout L = os_layout(b.sort_temp, (size_t)R);
+    const unsigned begin_bit = 32u, end_bit = 32u + bit;
+    const unsigned places = (bit + OS.radix_bits_per_place - 1) / OS.radix_bits_per_place;
+    const uint32_t size = (uint32_t)R;
+    {   // digit histograms of all places in one pass over the keys, then one exclusive scan per place (rocPRIM: radix_sort_onesweep_global_offsets)
+        const uint32_t blocks = (size + OS_HIST_ITEMS - 1) / OS_HIST_ITEMS, full_blocks = size % OS_HIST_ITEMS == 0 ? blocks : blocks - 1;
+        hipLaunchKernelGGL(os_histograms_kernel, dim3(blocks), dim3(OS.histogram.block_size), 0, st, b.keys_unsorted, L.offsets, size, full_blocks, begin_bit, end_bit);
+        hipLaunchKernelGGL(os_scan_histograms_kernel, dim3(places), dim3(OS.histogram.block_size), 0, st, L.offsets);
+    }
+    const uint32_t blocks = L.sort_blocks, full_blocks = size % OS_SORT_ITEMS == 0 ? blocks : blocks - 1;
+    bool to_output = (places - 1) % 2 == 0, from_input = true; // (ping-pong through the temporaries so that the last pass lands in the output arrays)
+    for (unsigned place = 0, pbit = begin_bit; place < places; place++, pbit += OS.radix_bits_per_place) {
+        const uint64_t* kin = from_input ? b.keys_unsorted : (to_output ? L.keys_tmp : b.keys);
+        const uint32_t* vin = from_input ? b.point_list_unsorted : (to_output ? L.values_tmp : b.point_list);
+        uint64_t* kout = to_output ? b.keys : L.keys_tmp;
+        uint32_t* vout = to_output ? b.point_list : L.values_tmp;
+        const unsigned radix_bits = end_bit - pbit < OS.radix_bits_per_place ? end_bit - pbit : OS.radix_bits_per_place;
+        hipLaunchKernelGGL(os_iteration_kernel, dim3(blocks), dim3(OS.sort.block_size), 0, st, kin, kout, vin, vout, size, L.offsets + place * OS_RADIX, L.offsets_tmp,
+                           L.lookback + (size_t)place * OS_RADIX * blocks, pbit, radix_bits, full_blocks, OsBlockId::create(L.block_ids + place));
+        from_input = false;
+        to_output = !to_output;
+    }
+    return hipGetLastError();
 }
 
 // ---- binning by tile counters (STP_SORT=counters; not the default, see stp_api.hip) ----------------------------------

@@ -166,10 +166,11 @@ hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st);
 hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st); // second level of the scan + the hand-over
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays; cap: slots of a run-ahead launch (0xFFFFFFFF = exact)
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t* zero_ptr, size_t zero_words, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays; cap: slots of a run-ahead launch (0xFFFFFFFF = exact)
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);
-hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, hipStream_t st);
+hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, bool zeroed, hipStream_t st); // zeroed: duplicate_kernel cleared sort_zero_region()
+void sort_zero_region(const BinningState& b, size_t R, uint32_t** ptr, size_t* words); // what the tile-bit sort's own driver needs cleared in front of it
 hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, bool unordered, hipStream_t st);
 hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st);

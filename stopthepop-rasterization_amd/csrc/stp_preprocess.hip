@@ -438,8 +438,11 @@ struct DupArgs {
     uint32_t* tile_cursor; // binning by tile counters: next free slot of every tile's segment (nullptr: slots by point_offsets)
     uint32_t cap;          // slots the arrays hold: a run-ahead forward (stp_api.hip) launches on a capacity, not on num_rendered; 0xFFFFFFFF = exact
     int n_gauss_blocks;    // workgroups that own Gaussians; the DUP_PAD_BLOCKS behind them fill [num_rendered, cap) with padding entries
+    int n_pad_blocks;      // DUP_PAD_BLOCKS for a capacity launch, else 0
+    uint32_t* zero_ptr;    // cleared by the DUP_ZERO_BLOCKS workgroups behind those: the tile-bit sort's histograms, look-back states and block
+    uint32_t zero_words;   // counters (stp_binning.hip: sort_zero_region), which the library's own driver clears with five separate fill launches
 };
-constexpr int DUP_PAD_BLOCKS = 128;
+constexpr int DUP_PAD_BLOCKS = 128, DUP_ZERO_BLOCKS = 32;
 
 // key + write decision of ONE (Gaussian, tile) pair: reference duplicateWithKeys_extended, stopthepop_common.cuh:420-460
 struct DupGaussian { float2 xy; float4 co; float thr; float3 p0, p1, p2; float global_depth; };
@@ -466,6 +469,12 @@ __device__ __forceinline__ bool duplicate_tile(const DupArgs& a, const DupGaussi
 __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
 {
 #pragma clang fp contract(off)
+    if ((int)blockIdx.x >= a.n_gauss_blocks + a.n_pad_blocks) {
+        uint4* const z = reinterpret_cast<uint4*>(a.zero_ptr); // (256-byte aligned, a multiple of 64 words)
+        for (uint32_t i = ((uint32_t)blockIdx.x - (uint32_t)(a.n_gauss_blocks + a.n_pad_blocks)) * 256u + threadIdx.x; i < a.zero_words / 4u; i += (uint32_t)DUP_ZERO_BLOCKS * 256u)
+            z[i] = make_uint4(0u, 0u, 0u, 0u);
+        return;
+    }
     if ((int)blockIdx.x >= a.n_gauss_blocks) {
         // run-ahead forward: the sort and range passes behind this kernel run over `cap` slots; the slots behind the frame's true count (known
         // on the device: the two-level scan's grand total) become padding entries, which sort behind every tile (an overflowing frame -- count
@@ -620,7 +629,8 @@ hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* 
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, hipStream_t st)
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t* zero_ptr, size_t zero_words,
+                            hipStream_t st)
 {
     DupArgs a;
     a.P = f.P; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
@@ -631,7 +641,9 @@ hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const 
     const bool capped = cap != 0xFFFFFFFFu && g.block_prefix != nullptr && tile_cursor == nullptr; // (a capacity launch needs the count on the device)
     a.cap = capped ? cap : 0xFFFFFFFFu;
     a.n_gauss_blocks = (f.P + 255) / 256;
-    hipLaunchKernelGGL(duplicate_kernel, dim3(a.n_gauss_blocks + (capped ? DUP_PAD_BLOCKS : 0)), dim3(256), 0, st, a);
+    a.n_pad_blocks = capped ? DUP_PAD_BLOCKS : 0;
+    a.zero_ptr = zero_ptr; a.zero_words = (uint32_t)zero_words;
+    hipLaunchKernelGGL(duplicate_kernel, dim3(a.n_gauss_blocks + a.n_pad_blocks + (zero_words ? DUP_ZERO_BLOCKS : 0)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

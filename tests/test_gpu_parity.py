@@ -556,6 +556,35 @@ def test_scan_and_colour_stream_switches_change_nothing():
             assert np.array_equal(outs["default"][part], outs[name][part]), (name, part)
 
 
+@pytest.mark.parametrize("scene_kw", [
+    "P=5000, W=200, H=120, sigma_min=1.0, sigma_max=30.0, seed=23, camera='orbit'",
+    "P=40000, W=1280, H=720, sigma_min=1.0, sigma_max=12.0, seed=3, camera='orbit'",
+    "P=300, W=64, H=48, sigma_min=1.0, sigma_max=6.0, seed=4"], ids=["8bit_digits", "13_tile_bits", "tiny"])
+def test_tile_bit_sort_under_our_own_onesweep_driver(scene_kw):
+    """The tile-bit sort runs rocPRIM's onesweep kernels under our own driver (stp_binning.hip: every pass with its own look-back states
+    and block counter, all cleared once by duplicate_kernel's trailing workgroups -- instead of the library's five fill launches per
+    sort).  STP_TILE_SORT=own forces it for every size, =rocprim is the library call: same sorted keys, list and frame, also in a
+    run-ahead forward (GpuRun renders both ways), for one, two and (tiles < 256) a single digit place."""
+    import os, subprocess, sys, tempfile
+    code = ("import sys, numpy as np; sys.path[:0] = ['tests', 'stopthepop-rasterization_amd', '.']; import conftest;"
+            "from helpers import *; from diff_gaussian_rasterization import scenes;"
+            f"sc = scenes.make_scene({scene_kw});"
+            "g = GpuRun(sc, settings_dict(3, order=3, rect=True, tight=True, tbc=True, h44=True, lb=True));"
+            "np.savez(sys.argv[1], color=g.color, k=g.binning_array('keys'), l=g.binning_array('point_list'), n=np.int64(g.num_rendered),"
+            " r=g.image_array('ranges'), dm=g.grads['dL_dmeans3D'])")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        outs = {}
+        for name in ("own", "rocprim"):
+            f = os.path.join(d, name + ".npz")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, STP_TILE_SORT=name), cwd=root)
+            outs[name] = dict(np.load(f))
+    assert int(outs["own"]["n"]) > 0
+    for part in ("n", "k", "l", "r", "color"):
+        assert np.array_equal(outs["own"][part], outs["rocprim"][part]), part
+    assert _rel(outs["own"]["dm"], outs["rocprim"]["dm"]) < 1e-5
+
+
 def test_second_backward_after_buffer_recycling_fails_loudly():
     """retain_graph + a later forward that reuses the pooled scratch buffers: the second backward must raise instead
     of replaying somebody else's tile lists."""
