@@ -144,7 +144,10 @@ int stp_backward(int P, int D, int M, int R,
    caller has summed them across ranks) and writes every dL_d* output.  phases = 3 == stp_backward.
    phases bit 2 (value 4, with bit 0 and / or bit 1) = COMPACT records: grad_records is P x STP_GRAD_RECORD_USED floats (36 bytes per
    Gaussian, no padding) -- the buffer a tile-row shard all-reduces between the two halves crosses xGMI as it is, without a
-   pack / unpack copy on either side.  (The padded 64-byte record is what a single GPU wants: one line, one atomic request per flush.) */
+   pack / unpack copy on either side.  (The padded 64-byte record is what a single GPU wants: one line, one atomic request per flush.)
+   phases bit 3 (value 8, with bit 1) = the per-Gaussian half leaves grad_records ZERO-FILLED again: it reads every record the render
+   half can have written (those of the visible Gaussians) and clears it behind the read, so that a caller who keeps the buffer between
+   steps never zero-fills it after the first time (the fill is 64 B per Gaussian per step otherwise: 24 us at 1M, 0.14 ms at 6M). */
 int stp_backward_phases(int phases, int P, int D, int M, int R,
                         const float* background, int width, int height,
                         const StpSettings* settings,

@@ -28,6 +28,7 @@
 #include <dlfcn.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <string>
@@ -47,6 +48,8 @@ std::mutex g_mutex;
 std::map<int, std::vector<Pooled>> g_free;          // device -> free buffers (oldest first)
 std::unordered_map<uintptr_t, int64_t> g_generation; // data_ptr -> how often the buffer at this address was handed out
 std::unordered_map<uintptr_t, hipEvent_t> g_events;  // data_ptr -> the event that orders reuse of the buffer at this address
+struct KeptRecords { torch::Tensor t; hipStream_t stream; };
+std::map<int, KeptRecords> g_records;               // device -> the gradient-record buffer of the last whole backward (all zeros at rest)
 int g_keep = 4;                                       // free buffers kept per device
 int64_t g_max_bytes = -1;                             // optional cap on the pooled bytes per device
 
@@ -265,7 +268,23 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
     const auto fopt = means3D.options().dtype(torch::kFloat32);
     const int rec_floats = (phases & 4) ? STP_GRAD_RECORD_USED : STP_GRAD_RECORD_FLOATS; // (bit 2: compact records, the tile-row shard's wire format)
-    torch::Tensor records = partial.has_value() ? *partial : torch::zeros({P, rec_floats}, fopt);
+    // STP_KEEP_RECORDS=1 (MEASURED, round 4, off): a whole backward keeps its record buffer between steps and the per-Gaussian half clears what
+    // it reads (phases bit 3), so that the 64 B per Gaussian are zero-filled once, not every step.  One buffer per device, reused only by the
+    // stream that used it last and only at the same size.  The clearing stores cost the per-Gaussian kernel more than torch's fill saves:
+    // C2-full step 2.376 -> 2.384 ms (BwdPreprocess 0.116 -> 0.126), C5 6.25 -> 6.39 ms (0.72-0.80 -> 0.90), C3 unchanged
+    // (profiles/r04_keep_records_ab.txt) -- a 7 TB/s fill kernel is hard to beat with scattered 48-byte stores.
+    static const bool keep_enabled = [] { const char* e = std::getenv("STP_KEEP_RECORDS"); return e && e[0] == '1'; }();
+    const bool keep_records = keep_enabled && phases == 3 && !partial.has_value() && P != 0;
+    torch::Tensor records;
+    hipStream_t rec_stream = nullptr;
+    if (keep_records) {
+        rec_stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        std::lock_guard<std::mutex> lock(g_mutex);
+        auto it = g_records.find(dev.index());
+        if (it != g_records.end() && it->second.stream == rec_stream && it->second.t.size(0) == P && it->second.t.size(1) == rec_floats) records = it->second.t;
+        if (it != g_records.end()) g_records.erase(it); // (in use, or superseded)
+    }
+    if (!records.defined()) records = partial.has_value() ? *partial : torch::zeros({P, rec_floats}, fopt);
     TORCH_CHECK(records.dim() == 2 && records.size(0) == P && records.size(1) == rec_floats && records.scalar_type() == torch::kFloat32 &&
                     records.is_contiguous(), "partial must be a contiguous float32 (P,", rec_floats, ") tensor");
     torch::Tensor dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
@@ -289,13 +308,17 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
         auto optb = [](const torch::Tensor& t) -> char* { return t.defined() && t.numel() != 0 ? reinterpret_cast<char*>(t.data_ptr()) : nullptr; };
         const c10::hip::HIPGuard guard(dev.index());
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
-        const int rc = g_api.backward_phases(phases, P, degree, M, R, fptr(bg_), W, H, &s, fptr(m3_), fptr(sh_), fptr(op_), fptr(col_), fptr(sc_),
+        const int rc = g_api.backward_phases(keep_records ? (phases | 8) : phases, P, degree, M, R, fptr(bg_), W, H, &s, fptr(m3_), fptr(sh_), fptr(op_), fptr(col_), fptr(sc_),
                                            scale_modifier, fptr(ro_), fptr(c3_), fptr(vm_), fptr(pm_), fptr(inv_), fptr(cam_), tan_fovx, tan_fovy,
                                            fptr(pix_), radii_.numel() ? radii_.data_ptr<int>() : nullptr, optb(geomBuffer), optb(binningBuffer),
                                            optb(imageBuffer), fptr(dl_), optf(dL_dmeans2D), records.data_ptr<float>(), optf(dL_dopacity), optf(dL_dcolors),
                                            optf(dL_dmeans3D), optf(dL_dcov3D), optf(dL_dsh), optf(dL_dscales), optf(dL_drotations), debug ? 1 : 0,
                                            (void*)stream);
         if (rc < 0) raise_last(rc);
+        if (keep_records) { // all zeros again once the kernels just enqueued have run
+            std::lock_guard<std::mutex> lock(g_mutex);
+            g_records[dev.index()] = KeptRecords{records, rec_stream};
+        }
     }
     if ((phases & 3) == 1) return {records};
     return {dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations};
@@ -351,6 +374,11 @@ int64_t clear_scratch_pool(int device) // device < 0: all devices; returns the b
         if (device >= 0 && it->first != device) { ++it; continue; }
         for (auto& p : it->second) freed += p.t.numel();
         it = g_free.erase(it);
+    }
+    for (auto it = g_records.begin(); it != g_records.end();) { // the kept gradient-record buffer goes too
+        if (device >= 0 && it->first != device) { ++it; continue; }
+        freed += it->second.t.numel() * (int64_t)sizeof(float);
+        it = g_records.erase(it);
     }
     return freed;
 }

@@ -32,6 +32,7 @@ struct BwdPreArgs {
     const float* cam;
     const float* grad_rec; // P x grad_stride: sums of the render half (layout: stp_raster.h, stp_backward)
     int grad_stride;       // 16 (one line per Gaussian, two 16-byte loads) or 9 (compact records of a tile-row shard)
+    int clear_rec;         // leave every record read zero-filled again (phases bit 3): the caller's buffer is ready for the next backward
     float* dL_dmean2D;     // P x 3  (out)
     float* dL_dopacity;    // P      (out)
     float* dL_dcolor;      // P x 3  (out)
@@ -62,6 +63,16 @@ __device__ __forceinline__ void gaussian_backward(const BwdPreArgs& a, int idx, 
         rec0 = make_float4(r[0], r[1], r[2], r[3]);
         rec1 = make_float4(r[4], r[5], r[6], r[7]);
         rec_op = r[8];
+    }
+    if (a.clear_rec) { // only records of visible Gaussians are ever written by the render half, and all of those pass through here
+        float* const r = const_cast<float*>(a.grad_rec) + (size_t)a.grad_stride * idx;
+        if (a.grad_stride == 16) {
+            const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            reinterpret_cast<float4*>(r)[0] = z; reinterpret_cast<float4*>(r)[1] = z; reinterpret_cast<float4*>(r)[2] = z;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) r[k] = 0.0f;
+        }
     }
     a.dL_dcolor[3 * (size_t)idx] = rec0.x; a.dL_dcolor[3 * (size_t)idx + 1] = rec0.y; a.dL_dcolor[3 * (size_t)idx + 2] = rec0.z;
     a.dL_dmean2D[3 * (size_t)idx] = rec0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = rec1.x;
@@ -356,7 +367,7 @@ hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState&
     a.means3D = f.means3D; a.radii = radii; a.shs = f.shs; a.clamped = g.clamped; a.opacities = f.opacities; a.scales = f.scales;
     a.rotations = f.rotations; a.cov3Ds = f.cov3D_precomp ? f.cov3D_precomp : g.cov3D; // reference rasterizer_impl.cu:500
     a.view = f.viewmatrix; a.proj = f.projmatrix; a.cam = f.cam_pos;
-    a.dL_dmean2D = bw.dL_dmean2D; a.grad_rec = bw.grad_rec; a.grad_stride = bw.grad_stride; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
+    a.dL_dmean2D = bw.dL_dmean2D; a.grad_rec = bw.grad_rec; a.grad_stride = bw.grad_stride; a.clear_rec = bw.clear_rec; a.dL_dopacity = bw.dL_dopacity; a.dL_dcolor = bw.dL_dcolor;
     a.dL_dmean3D = bw.dL_dmean3D; a.dL_dcov3D = bw.dL_dcov3D; a.dL_dsh = bw.dL_dsh; a.dL_dscale = bw.dL_dscale; a.dL_drot = bw.dL_drot;
     const size_t lds = (a.shs != nullptr && a.M > 0) ? (size_t)256 * (3 * a.M + 1) * sizeof(float) : 0;
     if (lds > 64 * 1024) { // above the default dynamic-LDS limit (M > 21: no SH degree the reference knows)

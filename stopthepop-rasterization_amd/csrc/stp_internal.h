@@ -149,6 +149,7 @@ struct BackwardParams {
     const float* dL_dpix;
     float* grad_rec;    // P x grad_stride: written by the render half, read by the per-Gaussian half
     int grad_stride;    // STP_GRAD_RECORD_FLOATS, or STP_GRAD_RECORD_USED with phases bit 2 (compact records)
+    int clear_rec;      // phases bit 3: the per-Gaussian half zero-fills the records again
     float* dL_dmean2D;  // outputs of the per-Gaussian half from here on
     float* dL_dopacity;
     float* dL_dcolor;

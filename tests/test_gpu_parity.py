@@ -733,3 +733,22 @@ def test_run_ahead_overflow_is_redone(sd):
     assert _layout_count(c) > c.num_rendered and np.array_equal(c.color, b.color)
     d = GpuRun(small, sd, backward=False, warm=False, run_ahead=True)   # and a small frame behind a big one is padded, not redone
     assert _layout_count(d) > 2 * d.num_rendered and np.array_equal(d.color, a.color)
+
+
+def test_gradient_record_buffer_is_kept_clean_between_backwards():
+    """The (P, 16) gradient-record buffer of a whole backward is kept by the binding and NOT zero-filled again: the per-Gaussian half clears
+    every record it reads (stp_backward_phases, phases bit 3).  Different scenes of one size back to back -- other visible sets, other modes --
+    must each get their own gradients, not the previous frame's leftovers."""
+    scs = [scenes.make_scene(P=4000, W=96, H=80, sigma_min=2.0, sigma_max=12.0, seed=s, camera="orbit") for s in (31, 32)]
+    scs[1].means3D[::3, 2] = -5.0    # a third of the second scene's Gaussians behind the camera: invisible there, visible in the first
+    for sc, sd in ((scs[0], settings_dict(**FULL_STP)), (scs[1], settings_dict(2, per_pixel=8)), (scs[0], settings_dict(0)), (scs[1], settings_dict(3))):
+        g = GpuRun(sc, sd, backward=True, warm=False)
+        f, og = oracle_run(sc, sd, backward=True)
+        for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"):
+            a, b = g.grads[k], og[k]
+            if k == "dL_dmeans2D":
+                a, b = a[:, :2], b[:, :2]
+            assert _rel(a, b) < 1e-4, k
+        invisible = f.radii == 0
+        assert invisible.any() or sc is scs[0]
+        assert not np.any(g.grads["dL_dmeans3D"][invisible]) and not np.any(g.grads["dL_dsh"][invisible])
