@@ -624,6 +624,14 @@ def main():
                            "insts_per_pair": round(64.0 * prof["SQ_INSTS_VALU"] / B, 1) if B else None,
                            "lane_util": round(prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"] / 64.0, 3),
                            "source": prof_note}
+            # the VALU roofline beside the HBM one (the kernel is VALU-issue bound): wave-instructions per second against the chip's full-rate issue,
+            # one wave64 fp32 instruction per SIMD every 2 cycles (157 TFLOP/s fp32 vector = 1024 SIMDs x 2.4 GHz x 64 lanes x 2 flop / 2 cycles);
+            # most of this kernel's stream issues at half that rate (compares, selects, min/max, DPP operands: profiles/valu_rate_bench)
+            t_prof = float(prof.get("avg_ms_at_profile", dom_ms)) * 1e-3
+            peak = 1024 * 2.4e9 / 2.0
+            out["roofline_valu"] = {"bound": "valu", "kernel": kname, "achieved": round(prof["SQ_INSTS_VALU"] / t_prof / 1e9, 1), "peak": round(peak / 1e9, 1),
+                                    "unit": "G wave-instructions/s", "frac": round(prof["SQ_INSTS_VALU"] / t_prof / peak, 4),
+                                    "how": "SQ_INSTS_VALU per launch / launch duration of the same rocprofv3 pass, against 1024 SIMDs x 2.4 GHz / 2 cycles"}
         return out
 
     def summary(o):
