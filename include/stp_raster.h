@@ -171,9 +171,17 @@ int stp_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 size_t stp_geometry_buffer_size(int P, const StpSettings* settings);
 size_t stp_binning_buffer_size(int R);
 size_t stp_image_buffer_size(int width, int height); /* without the optional blend log */
-/* Bytes the blend log adds to the image buffer of a forward with StpSettings.record_blend_log = 1 in the hierarchical / k-buffer modes
-   (514 B per pixel of the 16x16 tile grid): what a caller that holds several un-backpropagated forwards has to budget for. */
+/* Bytes the blend log adds to the image buffer of a forward with StpSettings.record_blend_log = 1 in the hierarchical / k-buffer modes,
+   for a frame nothing is known about yet: 192 records of 2 bytes per pixel of the 16x16 tile grid + one spare row = 386 B per pixel.
+   The depth is ADAPTIVE: every recording forward reports the largest number of blends of any of its pixels, and the next forwards of
+   the same kind (P, resolution, tile-row window, mode) on the device size their log by it (+12.5 %, multiple of 16, 32..512 records) --
+   258 B per pixel once a frame like BASELINE's C2 (at most 114 blends per pixel) has been seen, 450 B for C5 (195).  A pixel that blends
+   more than its frame's depth flags its tile, whose backward then re-sorts (correct, slow), and the frames after it get the deeper log.
+   STP_LOG_DEPTH=n in the environment fixes the depth.  _rows: of a forward restricted to the tile rows [tile_y0, tile_y1). */
 size_t stp_blend_log_bytes(int width, int height);
+size_t stp_blend_log_bytes_rows(int width, int height, int tile_y0, int tile_y1);
+/* The depth (records per pixel) of the blend log in an image buffer that a recording forward of this process filled. */
+int stp_blend_log_depth(const void* image_buffer);
 
 /* Introspection of the (otherwise opaque) scratch buffers, for parity tests and debugging.
    Fills byte offset and element count of a named sub-array; returns 0 or STP_ERR_INVALID_ARGUMENT.
@@ -199,6 +207,10 @@ void stp_reset_size_guesses(void);
 void stp_set_run_ahead(int enabled);
 int stp_get_run_ahead(void);
 int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count);
+/* ... of the image buffer of a forward restricted to the tile rows [tile_y0, tile_y1) (StpSettings::tile_y0 / tile_y1): it holds the
+   window's pixel rows and tiles only, element 0 of every sub-array being the window's first pixel / tile (0, 0 = the whole frame).
+   The count reported for "blend_log" is that of the default depth (see stp_blend_log_bytes). */
+int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const char* name, size_t* offset, size_t* count);
 
 /* Stage timer, the counterpart of the reference's `Timer` (rasterizer_impl.h:77-147; stages
    "Preprocess","Duplicate","Sort","Render", rasterizer_impl.cu:248) plus "BwdRender","BwdPreprocess".

@@ -150,7 +150,7 @@ GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total,
 // indexing by frame coordinates (pixel id W * y + x, tile id gx * ty + tx): the sub-array pointers handed to them are shifted back by the
 // window's first pixel row / tile, so that index -> address is unchanged inside the window and nothing outside it is ever touched (every
 // loop over tiles runs over [gx * ty0, gx * ty1), every kernel's grid over the window's tiles).
-ImageState carve_image(char* base, int W, int H, int ty0, int ty1, bool with_log, size_t* total, NamedOffset* names, int* n_names)
+ImageState carve_image(char* base, int W, int H, int ty0, int ty1, int log_depth, size_t* total, NamedOffset* names, int* n_names)
 {
     Carver c(base);
     ImageState s{};
@@ -171,8 +171,9 @@ ImageState carve_image(char* base, int W, int H, int ty0, int ty1, bool with_log
     // that is (wrongly) told a log exists -- e.g. after a render_depth forward -- replays nothing and re-sorts every tile
     // instead of reading a log that was never allocated.
     s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
-    const size_t recs_per_tile = 4 * (size_t)blend_log_rows() * 64; // 4 waves x rows x 64 lanes, 2 B each
-    if (with_log) { // blend log of the recording forward: [tile][wave][record][lane]
+    const size_t recs_per_tile = 4 * (size_t)blend_log_rows(log_depth) * 64; // 4 waves x rows x 64 lanes, 2 B each
+    s.log_depth = log_depth;
+    if (log_depth > 0) { // blend log of the recording forward: [tile][wave][record][lane]
         const size_t recs = T * recs_per_tile;
         s.blend_log = c.take<uint32_t>(recs / 2, &off); note("blend_log", off, recs);
     }
@@ -245,6 +246,7 @@ static void fill_frame(FrameParams& f, int P, int D, int M, const float* backgro
     f.scales = scales; f.rotations = rotations; f.cov3D_precomp = cov3D_precomp; f.viewmatrix = viewmatrix; f.projmatrix = projmatrix;
     f.inv_viewprojmatrix = inv_viewprojmatrix; f.cam_pos = cam_pos; f.prefiltered = prefiltered;
     f.wild_cov = 1; // (until the forward has read the status word: the kernels with the domain check)
+    f.log_depth = 0; f.log_need = nullptr;
 }
 
 } // namespace stp
@@ -271,7 +273,8 @@ namespace {
 // on one device do not re-record each other's event)
 struct Mailbox { volatile uint32_t* host = nullptr; uint32_t* dev = nullptr; hipEvent_t ev = nullptr; hipEvent_t done = nullptr; int device = 0; uint32_t ticket = 0; };
 constexpr int MAX_DEVICES = 32, MAILBOX_RING = 8;
-struct MailboxRing { Mailbox slot[MAILBOX_RING]; std::atomic<unsigned> next{0}; std::atomic<bool> ready{false}; };
+struct MailboxRing { Mailbox slot[MAILBOX_RING]; std::atomic<unsigned> next{0}; std::atomic<bool> ready{false};
+                     uint32_t* log_need = nullptr; /* device words, one per guess slot: report_log_need (stp_blend.h) */ };
 MailboxRing g_mailboxes[MAX_DEVICES];
 std::mutex g_mailbox_mutex;
 // Binning-size guesses: tile-list entries of the previous forward OF THE SAME KIND on each device.  "Kind" = (P, width,
@@ -279,7 +282,7 @@ std::mutex g_mailbox_mutex;
 // second rasterizer module) does not inherit the big frame's count.  Direct-mapped, 16 kinds per device; a collision only
 // costs the second allocator call.
 constexpr int GUESS_SLOTS = 16;
-struct SizeGuess { std::atomic<uint64_t> key{0}; std::atomic<uint32_t> R{0}; };
+struct SizeGuess { std::atomic<uint64_t> key{0}; std::atomic<uint32_t> R{0}; std::atomic<uint32_t> log_need{0}; }; // log_need: blends per pixel the kind's recording forwards needed
 SizeGuess g_guess[MAX_DEVICES][GUESS_SLOTS];
 uint64_t guess_key(const FrameParams& f)
 {
@@ -350,6 +353,31 @@ uint32_t layout_of(const void* binning, uint32_t R)
 
 std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && e[0] == '1') ? 1 : 0; }()};
 
+// ... and which depth an image buffer's blend log was carved with (the backward is handed the pointer only)
+std::unordered_map<const void*, uint32_t> g_log_depth;
+void remember_log_depth(const void* image, uint32_t depth)
+{
+    std::lock_guard<std::mutex> l(g_layout_mutex);
+    if (g_log_depth.size() > 8192 && g_log_depth.find(image) == g_log_depth.end()) g_log_depth.erase(g_log_depth.begin());
+    g_log_depth[image] = depth;
+}
+uint32_t log_depth_of(const void* image)
+{
+    std::lock_guard<std::mutex> l(g_layout_mutex);
+    const auto it = g_log_depth.find(image);
+    return it != g_log_depth.end() ? it->second : (uint32_t)blend_log_default_depth();
+}
+// Depth of this frame's blend log: the largest blend count per pixel that the recording forwards of this kind reported (slowly forgotten:
+// read_mailbox), + 12.5 % + 4, rounded up to 16 records; a frame nothing is known about gets the default.  STP_LOG_DEPTH=n fixes it.
+int log_depth_for(const SizeGuess& slot, uint64_t key)
+{
+    static const int fixed = [] { const char* e = std::getenv("STP_LOG_DEPTH"); return e ? std::atoi(e) : 0; }();
+    if (fixed > 0) return blend_log_clamp_depth((fixed + 1) & ~1);
+    const uint32_t need = slot.key.load(std::memory_order_acquire) == key ? slot.log_need.load(std::memory_order_relaxed) : 0u;
+    if (need == 0) return blend_log_default_depth();
+    return blend_log_clamp_depth((int)((need + need / 8 + 4 + 15) & ~15u));
+}
+
 int acquire_mailbox(Mailbox* out)
 {
     int device = 0;
@@ -369,6 +397,8 @@ int acquire_mailbox(Mailbox* out)
                 ring.slot[i].dev = static_cast<uint32_t*>(d);
                 ring.slot[i].device = device;
             }
+            if (hipMalloc(reinterpret_cast<void**>(&ring.log_need), sizeof(uint32_t) * 64) != hipSuccess || hipMemset(ring.log_need, 0, sizeof(uint32_t) * 64) != hipSuccess)
+                return fail(STP_ERR_HIP, "cannot create the blend-log depth words");
             ring.ready.store(true, std::memory_order_release);
         }
     }
@@ -399,7 +429,7 @@ size_t stp_binning_buffer_size(int R)
 size_t stp_image_buffer_size(int width, int height)
 {
     size_t total = 0;
-    carve_image(nullptr, width, height, 0, (height + TILE - 1) / TILE, false, &total);
+    carve_image(nullptr, width, height, 0, (height + TILE - 1) / TILE, 0, &total);
     return total;
 }
 
@@ -416,8 +446,8 @@ size_t stp_blend_log_bytes_rows(int width, int height, int tile_y0, int tile_y1)
 {
     clamp_rows(height, tile_y0, tile_y1);
     size_t plain = 0, with_log = 0;
-    carve_image(nullptr, width, height, tile_y0, tile_y1, false, &plain);
-    carve_image(nullptr, width, height, tile_y0, tile_y1, true, &with_log);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, 0, &plain);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, blend_log_default_depth(), &with_log); // (a frame nothing is known about: see stp_raster.h)
     return with_log - plain;
 }
 
@@ -450,8 +480,17 @@ int stp_get_run_ahead(void) { return g_run_ahead.load(std::memory_order_relaxed)
 void stp_reset_size_guesses(void)
 {
     for (auto& dev : g_guess)
-        for (auto& slot : dev) { slot.key.store(0, std::memory_order_release); slot.R.store(0u, std::memory_order_relaxed); }
+        for (auto& slot : dev) { slot.key.store(0, std::memory_order_release); slot.R.store(0u, std::memory_order_relaxed); slot.log_need.store(0u, std::memory_order_relaxed); }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    for (int d = 0; d < MAX_DEVICES; d++) // ... and what recording forwards have reported but no forward has collected yet
+        if (g_mailboxes[d].ready.load(std::memory_order_acquire) && g_mailboxes[d].log_need && hipSetDevice(d) == hipSuccess) {
+            (void)hipDeviceSynchronize();
+            (void)hipMemset(g_mailboxes[d].log_need, 0, sizeof(uint32_t) * 64);
+        }
+    (void)hipSetDevice(cur);
 }
+int stp_blend_log_depth(const void* image_buffer) { return (int)log_depth_of(image_buffer); }
 int stp_binning_layout_count(const void* binning_buffer, int R)
 {
     return (int)layout_of(binning_buffer, (uint32_t)(R > 0 ? R : 0));
@@ -460,7 +499,7 @@ int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const
 {
     NamedOffset names[16]; int n = 0;
     clamp_rows(height, tile_y0, tile_y1);
-    carve_image(nullptr, width, height, tile_y0, tile_y1, true, nullptr, names, &n);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, blend_log_default_depth(), nullptr, names, &n);
     return find_name(names, n, name, offset, count);
 }
 int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count)
@@ -554,13 +593,22 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     GeometryState g = carve_geometry(geom_ptr, (size_t)P, with_inv, nullptr);
     if (!radii) radii = g.internal_radii;
 
-    const size_t T = (size_t)f.gx * f.gy;
+    Mailbox mb; // (taken here already: the device's guess slots size the blend log)
+    if (int rc = acquire_mailbox(&mb)) return rc;
+    const uint64_t gkey = guess_key(f);
+    const unsigned gidx = (unsigned)((gkey >> 1) % GUESS_SLOTS);
+    SizeGuess& gslot = g_guess[mb.device][gidx];
+    uint32_t* const log_need_word = g_mailboxes[mb.device].log_need + gidx;
     size_t img_bytes = 0;
     const bool with_log = uses_blend_log(*settings);
-    carve_image(nullptr, width, height, f.ty0, f.ty1, with_log, &img_bytes); // (the tile-row window's share: see carve_image)
+    const int log_depth = with_log ? log_depth_for(gslot, gkey) : 0;
+    f.log_depth = log_depth;
+    f.log_need = with_log ? log_need_word : nullptr;
+    carve_image(nullptr, width, height, f.ty0, f.ty1, log_depth, &img_bytes); // (the tile-row window's share: see carve_image)
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
-    ImageState img = carve_image(img_ptr, width, height, f.ty0, f.ty1, with_log, nullptr);
+    ImageState img = carve_image(img_ptr, width, height, f.ty0, f.ty1, log_depth, nullptr);
+    if (with_log) remember_log_depth(img_ptr, (uint32_t)log_depth);
 
     // How the (tile, depth) order is established:
     //   default           device-wide radix sort on the tile bits only (two passes), then the tile's own workgroup sorts its
@@ -594,10 +642,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // pageable memory).  Here a one-thread kernel drops the two words into host-mapped pinned memory and an event marks
     // the spot; the SH -> RGB kernel -- which nothing before the render stage depends on -- is enqueued BEHIND it, so
     // the GPU keeps working while the host wakes up, sizes the buffer and launches duplicate / sort.
-    Mailbox mb;
-    if (int rc = acquire_mailbox(&mb)) return rc;
-    if (two_level_scan) STP_TRY(launch_block_prefix_mailbox(f, g, mb.dev, mb.ticket, st), "workgroup prefixes + mailbox launch");
-    else STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, mb.ticket, st), "mailbox launch");
+    if (two_level_scan) STP_TRY(launch_block_prefix_mailbox(f, g, mb.dev, mb.ticket, log_need_word, st), "workgroup prefixes + mailbox launch");
+    else STP_TRY(launch_mailbox(g.point_offsets + (P - 1), g.status + 1, mb.dev, mb.ticket, log_need_word, st), "mailbox launch");
     STP_TRY(hipEventRecord(mb.ev, st), "record mailbox event");
     SideStream* const side = side_stream(mb.device);
     SideJoin colours{mb.done, st, false};
@@ -645,8 +691,6 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     const bool run_ahead = g_run_ahead.load(std::memory_order_relaxed) != 0;
     size_t bin_have = 0;
     char* bin_ptr = nullptr;
-    const uint64_t gkey = guess_key(f);
-    SizeGuess& gslot = g_guess[mb.device][(gkey >> 1) % GUESS_SLOTS];
     const uint32_t guess = (speculative && gslot.key.load(std::memory_order_acquire) == gkey) ? gslot.R.load(std::memory_order_relaxed) : 0u;
     const bool ahead = run_ahead && guess > 0 && two_level_scan && !atomic_bin && !debug;
     const uint32_t cap = guess + guess / 8 + (ahead ? 1024u : 0u);
@@ -717,6 +761,11 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     auto read_mailbox = [&](int* R_out, bool* wild_out) -> int {
         if (int rc = wait_mailbox()) return rc;
         const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
+        if (const uint32_t reported = mb.host[3]) { // blends per pixel of the kind's last recording forward(s): never less than 31/32 of what was known
+            const uint32_t known = gslot.key.load(std::memory_order_acquire) == gkey ? gslot.log_need.load(std::memory_order_relaxed) : 0u;
+            const uint32_t keep = known - known / 32;
+            gslot.log_need.store(reported > keep ? reported : keep, std::memory_order_relaxed);
+        } else if (gslot.key.load(std::memory_order_acquire) != gkey) gslot.log_need.store(0u, std::memory_order_relaxed); // (the slot changes hands)
         if (host_status[1] & 1u) return fail(STP_ERR_PREFILTERED, "Point is filtered although prefiltered is set. This shouldn't happen!");
         *wild_out = (host_status[1] & 2u) != 0;
         *R_out = (int)host_status[0];
@@ -787,7 +836,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     const bool with_inv = requires_depth_along_ray(*settings);
     GeometryState g = carve_geometry(geom_buffer, (size_t)P, with_inv, nullptr);
     BinningState b = carve_binning(binning_buffer, (size_t)layout_of(binning_buffer, (uint32_t)(R > 0 ? R : 0)), nullptr); // (a run-ahead forward carved it for its capacity)
-    ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, uses_blend_log(*settings), nullptr);
+    ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, uses_blend_log(*settings) ? (int)log_depth_of(image_buffer) : 0, nullptr);
     if (!radii) radii = g.internal_radii;
 
     BackwardParams bw;

@@ -40,6 +40,11 @@ size_t scan_temp_bytes(size_t P)
 // launch_sort() with every pass owning its OWN look-back states and block counter, so that all of them are zeroed ONCE -- by trailing
 // workgroups of duplicate_kernel, which runs in front of the sort anyway (BinningState::sort_zero).  Same passes, same stable order,
 // same sorted list bit for bit (STP_TILE_SORT=rocprim keeps the library call for comparison).
+// Per frame at C2 under the kernel trace (profiles/r04_sortprof.txt): the library 2 x 42.5 (passes) + 16.2 + 12.5 + five fills of 7.6 = 152 us,
+// this driver 2 x 56.7 + 13.2 + 11.4 = 138 us.  The passes themselves look slower here only because they START earlier: the SH colour kernel runs on
+// the side stream beside the sort, and without the fills in front of them the passes overlap more of it (clearing the states closer to a pass --
+// by the scan kernel, by the pass before -- or with a memset in front changed the passes' durations exactly as far as it delayed them).  What
+// counts is the stage: sort stage -10 .. -25 us on every workload (profiles/r04_tilesort_driver_ab.txt).
 namespace {
 namespace rpd = rocprim::detail;
 using OsConfig = rpd::wrapped_radix_sort_onesweep_config<rocprim::default_config, uint64_t, uint32_t>;

@@ -37,6 +37,8 @@ struct RenderArgs {
     // blend log (training forward -> replay backward): per (tile, wave, k, lane) the list position of the k-th
     // entry that lane's pixel blended; tile_flags[tile] != 0 marks a tile whose log overflowed
     uint32_t* blend_log;   // (storage; the records are log_t)
+    int log_depth;         // records per pixel this frame's log holds (host: log_depth_for; the backward gets the forward's value)
+    uint32_t* log_need;    // recording forwards: where the frame's largest blend count per pixel is reported (report_log_need), or nullptr
     uint32_t* tile_flags;
     int flag_mode; // resorting backward: 0 = all tiles, 1 = only tiles with tile_flags != 0
     // debug depth visualisation (StpSettings::debug_visualization == STP_DEBUG_DEPTH): the forward kernels write
@@ -52,25 +54,34 @@ constexpr int LOG_MAX_LIST = 65535;
 #ifndef STP_LOG_PACK
 #define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured)
 #endif
+// Depth of the log = records per pixel it can hold (2 B each; + one spare row, STP_LOG_UNCOND): a RUN-TIME value since round 4
+// (RenderArgs::log_depth), chosen per frame by the host from the blends per pixel the previous recording forwards of the same kind
+// needed (stp_api.hip: log_depth_for) -- C2 blends at most 114 entries per pixel, C3 155, C5 195 (profiles/r03_log_depth_stats.txt), so
+// one fixed depth either wastes memory or sends tiles to the re-sorting fallback, and ONE such tile costs 1.25 ms (profiles/r04_log_depth_ab.txt).
+// BLEND_LOG_DEPTH is the depth of a frame nothing is known about yet; a pixel that blends more flags its tile as before.
 #ifndef STP_LOG_DEPTH
-#define STP_LOG_DEPTH 208 // records per pixel the log can hold (2 B each; with the spare row 418 B per pixel of the tile grid).  256 until round 3.  The
-                          // blends per pixel of the BASELINE frames (profiles/r03_log_depth_stats.txt): C2 mean 65 / max 114, C3 99 / 155, C5 109 / 195.
-                          // MEASURED with 192 (round 4, profiles/r04_log_depth_ab.txt): C2 and C3 unchanged -- write traffic does not depend on the
-                          // depth, only written records cost -- but ONE tile of C5 overflows, and that one tile, re-sorted by a single workgroup
-                          // (the fallback of every overflow), takes 1.25 ms: backward render 1.54 -> 2.79 ms, 154 -> 129 frames/s.  A depth is
-                          // a cliff, not a slope: 208 is the smallest multiple of 16 that holds all five BASELINE frames (19 % less log than 256).
+#define STP_LOG_DEPTH 192
 #endif
-constexpr int BLEND_LOG_DEPTH = STP_LOG_DEPTH;
+constexpr int BLEND_LOG_DEPTH = STP_LOG_DEPTH, BLEND_LOG_DEPTH_MIN = 32, BLEND_LOG_DEPTH_MAX = 512;
 #ifndef STP_LOG_UNCOND
 #define STP_LOG_UNCOND 1 // 1: the hierarchical recording forward stores a record in EVERY head step, without a branch -- a step that does
                          // not blend writes into the slot of the lane's next record, which the next blend overwrites -- and only the
                          // cursor's advance is conditional.  Needs one spare row per wave for the stores behind the last record.
 #endif
-constexpr int BLEND_LOG_ROWS = BLEND_LOG_DEPTH + (STP_LOG_UNCOND ? 1 : 0); // rows of 64 records in one wave's slice of the log
-constexpr size_t LOG_WAVE_BYTES = (size_t)BLEND_LOG_ROWS * 64 * sizeof(log_t);
-__device__ __forceinline__ char* log_wave_slice(uint32_t* blend_log, int tile, int wave) // [tile][wave][record][lane]
+constexpr int BLEND_LOG_SPARE = STP_LOG_UNCOND ? 1 : 0; // rows of 64 records in one wave's slice = depth + BLEND_LOG_SPARE
+__host__ __device__ __forceinline__ size_t log_wave_bytes(int depth) { return (size_t)(depth + BLEND_LOG_SPARE) * 64 * sizeof(log_t); }
+__device__ __forceinline__ char* log_wave_slice(uint32_t* blend_log, int tile, int wave, int depth) // [tile][wave][record][lane]
 {
-    return reinterpret_cast<char*>(blend_log) + (size_t)(tile * 4 + wave) * LOG_WAVE_BYTES;
+    return reinterpret_cast<char*>(blend_log) + (size_t)(tile * 4 + wave) * log_wave_bytes(depth);
+}
+// what a recording forward reports back: the largest number of blends of any of its pixels (one compare per wave, an atomic only while
+// the maximum still rises), collected per device and kind and handed to the host with the next forward's num_rendered
+__device__ __forceinline__ void report_log_need(uint32_t* word, int nrec)
+{
+    int m = nrec;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if (word != nullptr && (threadIdx.x & 63) == 0 && (uint32_t)m > *reinterpret_cast<volatile uint32_t*>(word)) atomicMax(word, (uint32_t)m);
 }
 
 struct FwdPixel {

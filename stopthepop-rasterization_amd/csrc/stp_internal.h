@@ -91,7 +91,8 @@ struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges 
     uint32_t* tile_cursor; // T
     uint32_t* bin_total;   // 2
     uint32_t* tile_flags; // T   0 = this tile's log is valid, 1 = its log overflowed, 0xFFFFFFFF = the forward recorded no log
-    uint32_t* blend_log;  // T * 4 waves * BLEND_LOG_ROWS * 64 lanes of u16 (only with the blend log)
+    uint32_t* blend_log;  // T * 4 waves * (log_depth + spare) rows * 64 lanes of u16 (only with the blend log)
+    int log_depth;        // records per pixel the log holds (0: none)
 };
 
 struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
@@ -115,10 +116,12 @@ struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
 struct NamedOffset { const char* name; size_t offset; size_t count; };
 
 GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
-ImageState carve_image(char* base, int W, int H, int ty0, int ty1, bool with_log, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr); // the tile-row window's share, frame-coordinate indexing
+ImageState carve_image(char* base, int W, int H, int ty0, int ty1, int log_depth /* 0: no blend log */, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr); // the tile-row window's share, frame-coordinate indexing
 BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
 
-int blend_log_rows(); // rows of 64 records per wave in the blend log (stp_render_replay.hip: BLEND_LOG_ROWS of stp_blend.h)
+int blend_log_rows(int depth); // rows of 64 records per wave in a blend log of that depth (stp_render_replay.hip / stp_blend.h)
+int blend_log_default_depth(); // depth of a frame nothing is known about
+int blend_log_clamp_depth(int d);
 size_t scan_temp_bytes(size_t P);
 size_t sort_temp_bytes(size_t R);
 
@@ -141,6 +144,8 @@ struct FrameParams {
     const float* inv_viewprojmatrix;
     const float* cam_pos;
     int prefiltered;
+    int log_depth;       // depth of this frame's blend log (forward: chosen by log_depth_for; backward: the forward's)
+    uint32_t* log_need;  // forward: device word the recording kernels report their largest blend count per pixel to (or nullptr)
     int wild_cov; // forward, after the status read-back: some visible Gaussian has a Sigma^-1 entry >= 1e36 or not finite (depth keys then take the reciprocal with its domain check)
 };
 
@@ -165,8 +170,8 @@ hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* 
 hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int tile0, int n_tiles, bool with_log, bool tile_counters, hipStream_t st); // status, ranges, tile flags (+ tile counters) of the window's tiles
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
-hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st);
-hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st); // second level of the scan + the hand-over
+hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st);
+hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st); // second level of the scan + the hand-over
 hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t* zero_ptr, size_t zero_words, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays; cap: slots of a run-ahead launch (0xFFFFFFFF = exact)
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);

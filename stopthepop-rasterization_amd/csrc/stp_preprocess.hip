@@ -662,10 +662,12 @@ hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const i
 }
 
 // num_rendered (the scan's last element) and the status word into host-mapped memory: the forward's one host hand-over
-__global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const uint32_t* __restrict__ status, volatile uint32_t* mailbox, uint32_t ticket)
+__global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const uint32_t* __restrict__ status, volatile uint32_t* mailbox, uint32_t ticket,
+                               uint32_t* log_need)
 {
     mailbox[0] = *last_offset;
     mailbox[1] = *status;
+    mailbox[3] = log_need ? atomicExch(log_need, 0u) : 0u; // what the recording forwards before this one reported (stp_blend.h: report_log_need)
     __threadfence_system();
     mailbox[2] = ticket; // the host may be watching this word (stp_forward): it goes out after the two values
     __threadfence_system();
@@ -674,7 +676,8 @@ __global__ void mailbox_kernel(const uint32_t* __restrict__ last_offset, const u
 // Second level of the scan + the hand-over, one workgroup: exclusive scan of the preprocess workgroups' totals (thread t takes a run of
 // consecutive totals), num_rendered = the grand total and the status word into host-mapped memory, the ticket last (see mailbox_kernel).
 __global__ void __launch_bounds__(1024) block_prefix_mailbox_kernel(const uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_prefix, int n_blocks,
-                                                                     const uint32_t* __restrict__ status, volatile uint32_t* mailbox, uint32_t ticket)
+                                                                     const uint32_t* __restrict__ status, volatile uint32_t* mailbox, uint32_t ticket,
+                                                                     uint32_t* log_need)
 {
     __shared__ uint32_t s_wave_total[16];
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -695,21 +698,22 @@ __global__ void __launch_bounds__(1024) block_prefix_mailbox_kernel(const uint32
     if (tid == 1023) {
         mailbox[0] = v;
         mailbox[1] = status[1];
+        mailbox[3] = log_need ? atomicExch(log_need, 0u) : 0u; // (see mailbox_kernel)
         __threadfence_system();
         mailbox[2] = ticket;
         __threadfence_system();
     }
 }
 
-hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st)
+hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st)
 {
-    hipLaunchKernelGGL(block_prefix_mailbox_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_prefix, (f.P + 255) / 256, g.status, mailbox_dev, ticket);
+    hipLaunchKernelGGL(block_prefix_mailbox_kernel, dim3(1), dim3(1024), 0, st, g.block_sums, g.block_prefix, (f.P + 255) / 256, g.status, mailbox_dev, ticket, log_need);
     return hipGetLastError();
 }
 
-hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, hipStream_t st)
+hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st)
 {
-    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, last_offset, status, mailbox_dev, ticket);
+    hipLaunchKernelGGL(mailbox_kernel, dim3(1), dim3(1), 0, st, last_offset, status, mailbox_dev, ticket, log_need);
     return hipGetLastError();
 }
 

@@ -82,8 +82,9 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     };
 
     // blend log (recording forward): as in stp_render_hier.inc
-    char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w) : nullptr;
+    char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr;
     constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
+    const uint32_t log_cap = (uint32_t)a.log_depth * LOG_ROW;
 #if STP_LOG_PACK
     // packed log: a lane holds the first record of a pair and stores both as one dword -- every store of a wave that is in
     // step is a full 256-byte row
@@ -91,19 +92,19 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     int log_held = -1;                      // first record of the current pair, -1: none
     auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
         const bool second = log_held >= 0;
-        if (upd && second && log_off < (BLEND_LOG_DEPTH / 2) * 256u)
+        if (upd && second && log_off < (uint32_t)(a.log_depth / 2) * 256u)
             *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held | ((uint32_t)pay << 16);
         log_off += (upd && second) ? 256u : 0u;
         log_held = upd ? (second ? -1 : pay) : log_held;
     };
     auto log_records = [&]() __attribute__((always_inline)) -> int { return 2 * (int)(log_off >> 8) + (int)(log_held >= 0); };
     auto log_finish = [&]() __attribute__((always_inline)) { // the odd last record
-        if (log_held >= 0 && log_off < (BLEND_LOG_DEPTH / 2) * 256u) *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held;
+        if (log_held >= 0 && log_off < (uint32_t)(a.log_depth / 2) * 256u) *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held;
     };
 #else
     uint32_t log_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
     auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
-        if (upd && log_off < BLEND_LOG_DEPTH * LOG_ROW) *reinterpret_cast<log_t*>(log_wave + log_off) = (log_t)pay;
+        if (upd && log_off < log_cap) *reinterpret_cast<log_t*>(log_wave + log_off) = (log_t)pay;
         log_off += upd ? LOG_ROW : 0u;
     };
     auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_off / LOG_ROW); };
@@ -296,7 +297,8 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
         }
     }
     if constexpr (RECORD) {
-        if (log_records() > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u; // log overflow: this tile's backward re-sorts
+        if (log_records() > a.log_depth || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u; // log overflow: this tile's backward re-sorts
+        report_log_need(a.log_need, log_records());
     }
 }
 

@@ -4,7 +4,8 @@
 // three-level resort to rediscover the order in which every pixel blended its Gaussians.  MI355X has 288 GB of
 // HBM, so the training forward (render_hier_kernel<..., MODE_FWD_RECORD>, render_kbuffer_kernel<WIN, KB_FWD_RECORD>)
 // simply writes that order down -- 2 bytes (the tile-list position) per blended (pixel, Gaussian) pair,
-// BLEND_LOG_DEPTH = 192 records per pixel (+ one spare row: 386 B per pixel, 0.80 GB at 1080p) -- and this kernel walks each pixel's log
+// as many records per pixel as the frames before it needed (RenderArgs::log_depth; 192 + one spare row = 386 B per pixel for a frame nothing
+// is known about, 258 B per pixel = 0.54 GB at 1080p once C2's 114 blends per pixel are known) -- and this kernel walks each pixel's log
 // front to back.  The gradient maths per pair is the reference's (blend_backward_terms); the result is the same sum
 // in a different order.  Tiles whose log overflowed (a pixel with more than BLEND_LOG_DEPTH blended entries, a list longer than
 // 65535) are flagged by the forward and left to the re-sorting backward kernels, which then run only on those tiles.
@@ -180,7 +181,8 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     // Addressing: wave-uniform bases (SGPR pairs) + one 32-bit byte offset per load, so that the loop's loads are
     // `global_load ... v_off, s[base]` without 64-bit address arithmetic (v_lshl_add_u64 issues at half the rate of a
     // 32-bit add on gfx950, tools/valu_rate_bench.hip).
-    const char* const log_wave = log_wave_slice(a.blend_log, tile, __builtin_amdgcn_readfirstlane(w));
+    const char* const log_wave = log_wave_slice(a.blend_log, tile, __builtin_amdgcn_readfirstlane(w), a.log_depth);
+    const uint32_t log_last_row = (uint32_t)(a.log_depth + BLEND_LOG_SPARE - 1), log_last_rec = (uint32_t)(a.log_depth - 1);
     const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
     constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
     auto log_at = [&](uint32_t k) __attribute__((always_inline)) -> int { // record k of this lane
@@ -505,7 +507,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
         // requested at the top of a step, the log word of the one after next right behind it -- unconditionally (a row of the log that
         // holds no record of mine is readable garbage): nothing in a step waits for a load issued in the same step.
         int pos = (0 < n && off == 0) ? log_at(0) : -1;
-        int raw1 = log_at((uint32_t)min(max(1 - off, 0), BLEND_LOG_DEPTH - 1));
+        int raw1 = log_at(min((uint32_t)max(1 - off, 0), log_last_rec));
         Entry en = entry_at(max(pos, 0));
 #ifndef STP_REPLAY_UNROLL2
 #define STP_REPLAY_UNROLL2 1 // two copies of the step, the entry registers alternating between them (no copy of the ten entry words at the back edge)
@@ -520,7 +522,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             const int pos1 = have1 ? raw1 : -1;
             nxt = entry_at_clamped(have1 ? (uint32_t)raw1 : 0u);
-            raw1 = log_at(min((uint32_t)(kr + 2), (uint32_t)(BLEND_LOG_ROWS - 1)));
+            raw1 = log_at(min((uint32_t)(kr + 2), log_last_row));
             pos = pos1;
 #if !STP_REPLAY_HOIST && !STP_REPLAY_STRAIGHT
             for (int kk = 0; kk < 9; kk++) g[kk] = 0.0f;
@@ -590,7 +592,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
             const int cur_pos = pos, cur_id = __float_as_int(cur.c.w);
             // issue the next round of loads before touching this step's data
             k += (int)act;
-            const int rec = log_at((uint32_t)min(k + 1, BLEND_LOG_DEPTH - 1));
+            const int rec = log_at(min((uint32_t)(k + 1), log_last_rec));
             pos = act ? pos1 : pos;
             pos1 = act ? (k + 1 < n ? rec : EXHAUSTED) : pos1;
             en = entry_at(pos);
@@ -620,7 +622,9 @@ extern "C" int stp_debug_replay_stats(unsigned long long* out16)
 }
 #endif
 
-int blend_log_rows() { return BLEND_LOG_ROWS; }
+int blend_log_rows(int depth) { return depth + BLEND_LOG_SPARE; }
+int blend_log_default_depth() { return BLEND_LOG_DEPTH; }
+int blend_log_clamp_depth(int d) { return d < BLEND_LOG_DEPTH_MIN ? BLEND_LOG_DEPTH_MIN : (d > BLEND_LOG_DEPTH_MAX ? BLEND_LOG_DEPTH_MAX : d); }
 
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {

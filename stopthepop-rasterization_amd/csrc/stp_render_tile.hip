@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     else init_fwd_pixel(fp);
     uint32_t contributor = 0;
     float depth_acc = 0.0f;
-    log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(log_wave_slice(a.blend_log, c.tile, w)) + lane : nullptr;
+    log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(log_wave_slice(a.blend_log, c.tile, w, a.log_depth)) + lane : nullptr;
     int nrec = 0;
     const float4* const eF = a.entF + c.range.x;
     const float4* const eCl = a.entC + c.range.x;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             if constexpr (DEPTHVIZ) { if (ok) depth_acc += win.depth[0] * alpha0 * T_before; } // reference resorted_render.cuh:107
             if constexpr (RECORD) {
                 if (ok) {
-                    if (nrec < BLEND_LOG_DEPTH) log_base[(size_t)nrec * 64] = (log_t)pos;
+                    if (nrec < a.log_depth) log_base[(size_t)nrec * 64] = (log_t)pos;
                     nrec++;
                 }
             }
@@ -395,7 +395,8 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             }
         }
         if constexpr (RECORD) {
-            if (nrec > BLEND_LOG_DEPTH || total > LOG_MAX_LIST) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
+            if (nrec > a.log_depth || total > LOG_MAX_LIST) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
+            report_log_need(a.log_need, nrec);
         }
     }
 }
@@ -412,6 +413,7 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     a.final_T = img.final_T; a.n_contrib = img.n_contrib;
     a.blend_log = img.blend_log; a.tile_flags = img.tile_flags; a.flag_mode = 0;
+    a.log_depth = img.log_depth; a.log_need = f.log_need;
     a.debug_depth = f.s.debug_visualization == STP_DEBUG_DEPTH ? 1 : 0; a.means3D = f.means3D;
     return a;
 }

@@ -175,7 +175,8 @@ def backward_mode() -> str:
 
 
 def blend_log_bytes(width: int, height: int, tile_rows=None) -> int:
-    """Bytes of the blend log of one forward at this resolution (386 B per pixel of the 16x16 tile grid; the library's own figure).
+    """Bytes of the blend log of one forward at this resolution for a frame nothing is known about (386 B per pixel of the 16x16 tile
+    grid; the library's own figure -- later frames of the same kind get the depth their predecessors needed: blend_log_depth).
     tile_rows = (y0, y1): of a forward restricted to that tile-row window (a rank of a tile-row shard holds its rows' log only)."""
     L = _load()
     if tile_rows is None:
@@ -365,6 +366,14 @@ def image_array(imgBuffer, W, H, name, tile_rows=None):
     if L.stp_image_layout_rows(int(W), int(H), y0, y1, name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
         raise KeyError(name)
     return _view(imgBuffer, off.value, cnt.value, _IMG_TYPES[name])
+
+
+def blend_log_depth(imgBuffer) -> int:
+    """Records per pixel of the blend log in the image buffer of a recording forward (adaptive: include/stp_raster.h, stp_blend_log_bytes)."""
+    L = _load()
+    L.stp_blend_log_depth.argtypes = [ctypes.c_void_p]
+    L.stp_blend_log_depth.restype = ctypes.c_int
+    return int(L.stp_blend_log_depth(ctypes.c_void_p(imgBuffer.data_ptr())))
 
 
 def set_run_ahead(flag: bool) -> bool:

@@ -313,7 +313,7 @@ def test_backward_mode_auto_holds_eight_1080p_forwards_within_a_4GB_log_budget()
             total, recorded, peak = 0.0, 0, 0
             for i in range(K):
                 color, _ = rast(m3, m2, op, shs=sh, scales=scl, rotations=rot)
-                recorded += int(color.grad_fn.saved_tensors[11].numel() >= log_bytes)
+                recorded += int(getattr(color.grad_fn, "log_lease", None) is not None)   # (the buffer's size follows the scene: the lease says whether a log was recorded)
                 total = total + (color * w).sum() * (1.0 + 0.125 * i)
                 peak = max(peak, _C.live_log_bytes(dev))
             total.backward()
@@ -752,3 +752,38 @@ def test_gradient_record_buffer_is_kept_clean_between_backwards():
         invisible = f.radii == 0
         assert invisible.any() or sc is scs[0]
         assert not np.any(g.grads["dL_dmeans3D"][invisible]) and not np.any(g.grads["dL_dsh"][invisible])
+
+
+def test_blend_log_depth_follows_the_scene():
+    """The blend log's depth is chosen per frame (stp_api.hip: log_depth_for): a frame nothing is known about gets 192 records per pixel,
+    every recording forward reports the largest blend count of its pixels, and the frames of the same kind after it size their log by it
+    -- smaller for a scene that blends a few dozen entries per pixel, deeper (up to 512) for one that overflowed."""
+    from diff_gaussian_rasterization import _C
+    sd = settings_dict(**FULL_STP)
+    sc = scenes.make_scene(**DENSE)
+    _C.reset_size_guesses()
+    runs = [GpuRun(sc, sd, backward=True, warm=False) for _ in range(3)]
+    need = int(runs[0].image_array("n_contrib").view(np.uint32).max())
+    assert 8 < need < 165
+    assert _C.blend_log_depth(runs[0].img) == 192 and _C.blend_log_depth(runs[1].img) == 192    # (the second frame is sized before the first one's report arrives)
+    want = min(512, max(32, (need + need // 8 + 4 + 15) // 16 * 16))
+    assert _C.blend_log_depth(runs[2].img) == want and want < 192 and runs[2].img.numel() < runs[0].img.numel()
+    assert not runs[2].image_array("tile_flags").any()
+    for r in runs[1:]:
+        assert np.array_equal(r.color, runs[0].color)
+        for k in GRAD_KEYS:
+            if runs[0].grads.get(k) is not None:
+                assert _rel(r.grads[k], runs[0].grads[k]) < 1e-5, k
+    # a scene whose pixels blend more than 192 entries: flagged tiles (re-sorting backward) at first, a deeper log afterwards
+    hz = scenes.make_scene(P=4000, W=48, H=48, sigma_min=8.0, sigma_max=20.0, seed=9, opacity_range=(0.004, 0.012))
+    _C.reset_size_guesses()
+    h = [GpuRun(hz, sd, backward=True, warm=False) for _ in range(3)]
+    need_h = int(h[0].image_array("n_contrib").view(np.uint32).max())
+    assert 192 < need_h, need_h
+    assert h[0].image_array("tile_flags").any() and _C.blend_log_depth(h[0].img) == 192
+    assert _C.blend_log_depth(h[2].img) == min(512, (need_h + need_h // 8 + 4 + 15) // 16 * 16)
+    if need_h <= _C.blend_log_depth(h[2].img):
+        assert not h[2].image_array("tile_flags").any()
+    for k in GRAD_KEYS:
+        if h[0].grads.get(k) is not None:
+            assert _rel(h[2].grads[k], h[0].grads[k]) < 2e-5, k     # replayed == re-sorted
