@@ -199,12 +199,13 @@ int stp_binning_layout_count(const void* binning_buffer, int R);
    binning request are sized by: the next forward of every kind takes the reference's path again (hand-over in the middle of the frame,
    exact request).  For tests and benchmarks that want a defined starting state; never needed for correctness. */
 void stp_reset_size_guesses(void);
-/* Run-ahead forward (off by default; STP_RUN_AHEAD=1 in the environment switches it on at load time).  With it, every forward that has a
-   size guess (i.e. every forward but the first of its kind) enqueues ALL its kernels on the guessed capacity before it reads num_rendered
-   back -- no host wait in the middle of the frame; a frame that does not fit its guess is redone with the exact size before stp_forward
-   returns.  Results are identical either way (keys, lists, image, gradients).  Measured on MI355X it costs 0.5 % at C2 (the padded
-   entries pass through the device-wide sort) and is therefore an option: for hosts whose launching thread is stalled often. */
-void stp_set_run_ahead(int enabled);
+/* Run-ahead forward.  mode 0 = never, 1 = always, 2 = auto (the default; STP_RUN_AHEAD=0 / 1 in the environment sets 0 / 1 at load time).
+   With it, a forward that has a size guess (i.e. every forward but the first of its kind) enqueues ALL its kernels on the guessed capacity
+   before it reads num_rendered back -- no host wait in the middle of the frame; a frame that does not fit its guess is redone with the
+   exact size before stp_forward returns.  Results are identical either way (keys, lists, image, gradients).  Measured on MI355X it
+   costs 0.5 % at 1M Gaussians / 1080p (the padded entries pass through the device-wide sort) and gains 7 % at 1k Gaussians / 256x256
+   (the round trip is a tenth of that frame): auto = run ahead when the guess is below 2^18 tile-list entries. */
+void stp_set_run_ahead(int mode);
 int stp_get_run_ahead(void);
 int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count);
 /* ... of the image buffer of a forward restricted to the tile rows [tile_y0, tile_y1) (StpSettings::tile_y0 / tile_y1): it holds the

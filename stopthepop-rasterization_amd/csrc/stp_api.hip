@@ -351,7 +351,9 @@ uint32_t layout_of(const void* binning, uint32_t R)
     return it != g_layout.end() && it->second >= R ? it->second : R;
 }
 
-std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && e[0] == '1') ? 1 : 0; }()};
+// run-ahead forward: 0 = never, 1 = whenever a size guess exists, 2 (default) = for SMALL frames only (guess below RUN_AHEAD_AUTO_MAX entries)
+constexpr uint32_t RUN_AHEAD_AUTO_MAX = 1u << 18;
+std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2; }()};
 
 // ... and which depth an image buffer's blend log was carved with (the backward is handed the pointer only)
 std::unordered_map<const void*, uint32_t> g_log_depth;
@@ -475,7 +477,7 @@ int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count)
     carve_binning(nullptr, (size_t)(R > 0 ? R : 0), nullptr, names, &n);
     return find_name(names, n, name, offset, count);
 }
-void stp_set_run_ahead(int enabled) { g_run_ahead.store(enabled ? 1 : 0, std::memory_order_relaxed); }
+void stp_set_run_ahead(int mode) { g_run_ahead.store(mode < 0 ? 0 : (mode > 2 ? 2 : mode), std::memory_order_relaxed); }
 int stp_get_run_ahead(void) { return g_run_ahead.load(std::memory_order_relaxed); }
 void stp_reset_size_guesses(void)
 {
@@ -675,7 +677,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // TWICE per forward, the second time with the larger size (include/stp_raster.h).
     static const char* const bin_env = std::getenv("STP_BINNING");
     static const bool speculative = !(bin_env && std::strcmp(bin_env, "exact") == 0);
-    // RUN-AHEAD (round 4; off by default: STP_RUN_AHEAD=1 in the environment or stp_set_run_ahead(1) switch it on).  The reference -- and the
+    // RUN-AHEAD (round 4; by default for small frames only: STP_RUN_AHEAD=0 / 1 in the environment or stp_set_run_ahead(0 / 1 / 2) say never / always / auto).  The reference -- and the
     // default path here -- stop the host after the scan until num_rendered has come back, and only then enqueue duplicate / sort / render:
     // a stall of the launching thread there is GPU idle time.  With a size guess the whole forward is enqueued at once ON THE GUESSED
     // CAPACITY: the sub-arrays are carved for `cap` entries, duplicate_kernel guards its writes and pads [num_rendered, cap) with entries
@@ -686,13 +688,16 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     // MEASURED (one box, alternating, profiles/r04_run_ahead_ab.txt): the padding costs the device-wide passes what it weighs -- C2-full sort
     // stage 0.325 -> 0.343 ms, step 2.410 -> 2.422 ms; C5 +0.04 ms; C4 +0.03 ms -- and nothing comes back: the hand-over bubble was already
     // hidden (mailbox word + colour kernel behind it), `ms_per_step - sum(stages)` stays at 0.04 ms, and C1 is bound by the ~25 launches of a
-    // step, not by the round trip.  Hence off by default; what it does buy is a frame whose GPU time no longer depends on the launching
-    // thread being scheduled in the middle of it.
-    const bool run_ahead = g_run_ahead.load(std::memory_order_relaxed) != 0;
+    // step, not by the round trip.  Hence off for large frames by default; what it does buy there is a frame whose GPU time no longer depends on
+    // the launching thread being scheduled in the middle of it.
+    // Small frames are the exception (mode 2, the default: guesses below 2^18 entries): there the padding weighs nothing and the round trip is
+    // a tenth of the frame -- C1 0.179 -> 0.167 ms per step (profiles/r04_host_profile_c1.txt).
+    const int run_ahead_mode = g_run_ahead.load(std::memory_order_relaxed);
+    const bool run_ahead = run_ahead_mode != 0;
     size_t bin_have = 0;
     char* bin_ptr = nullptr;
     const uint32_t guess = (speculative && gslot.key.load(std::memory_order_acquire) == gkey) ? gslot.R.load(std::memory_order_relaxed) : 0u;
-    const bool ahead = run_ahead && guess > 0 && two_level_scan && !atomic_bin && !debug;
+    const bool ahead = run_ahead && guess > 0 && (run_ahead_mode == 1 || guess < RUN_AHEAD_AUTO_MAX) && two_level_scan && !atomic_bin && !debug;
     const uint32_t cap = guess + guess / 8 + (ahead ? 1024u : 0u);
     if (guess > 0) {
         carve_binning(nullptr, (size_t)cap, &bin_have);

@@ -376,14 +376,15 @@ def blend_log_depth(imgBuffer) -> int:
     return int(L.stp_blend_log_depth(ctypes.c_void_p(imgBuffer.data_ptr())))
 
 
-def set_run_ahead(flag: bool) -> bool:
-    """Run-ahead forward on / off (include/stp_raster.h: stp_set_run_ahead); returns the previous setting.  Off by default."""
+def set_run_ahead(mode) -> int:
+    """Run-ahead forward: False / 0 = never, True / 1 = always, 2 = auto (small frames only; the default) -- include/stp_raster.h:
+    stp_set_run_ahead.  Returns the previous mode."""
     L = _load()
     L.stp_set_run_ahead.argtypes = [ctypes.c_int]
     L.stp_set_run_ahead.restype = None
     L.stp_get_run_ahead.restype = ctypes.c_int
-    prev = bool(L.stp_get_run_ahead())
-    L.stp_set_run_ahead(int(bool(flag)))
+    prev = int(L.stp_get_run_ahead())
+    L.stp_set_run_ahead(int(mode))
     return prev
 
 

@@ -76,7 +76,7 @@ class GpuRun:
         self.run_ahead_before = None
         if warm and not debug:
             _C.reset_size_guesses()
-            self.run_ahead_before = _C.set_run_ahead(False)
+            self.run_ahead_before = _C.set_run_ahead(0)
             empty_ = torch.Tensor([])
             e_ = lambda x: empty_ if x is None else x.detach()
             o = _C.rasterize_gaussians(rs.bg, self.means3D.detach(), e_(self.colors), self.opac.detach(), e_(self.scales), e_(self.rots),
@@ -86,9 +86,9 @@ class GpuRun:
             self.exact_pass = (int(o[0]), o[1].clone(), o[2].clone())
             _C.release_scratch(o[5]); _C.release_scratch(o[4])
             del o
-            _C.set_run_ahead(True)
+            _C.set_run_ahead(1)
         elif run_ahead is not None:
-            self.run_ahead_before = _C.set_run_ahead(bool(run_ahead))
+            self.run_ahead_before = _C.set_run_ahead(1 if run_ahead else 0)
         try:
             self._run(rast, rs, es, backward, dev, prefiltered, render_depth, debug)
         finally:
