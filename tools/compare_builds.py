@@ -29,6 +29,7 @@ for name, lib in (("A", libA), ("B", libB)):
     R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
     torch.cuda.synchronize()
     n = _C.image_array(img, sc.W, sc.H, "n_contrib").clone()
+    depth = _C.blend_log_depth(img)   # (the first forward of a kind in a library: the default depth, the one stp_image_layout reports "blend_log" for)
     out[name] = dict(R=R, color=color.clone(), list=_C.binning_array(binning, R, "point_list").clone(), keys=_C.binning_array(binning, R, "keys").clone(),
                      final_T=_C.image_array(img, sc.W, sc.H, "final_T").clone(), n=n, flags=_C.image_array(img, sc.W, sc.H, "tile_flags").clone(),
                      log=_C.image_array(img, sc.W, sc.H, "blend_log").clone())
@@ -50,9 +51,9 @@ lx, ly = px % 16, py % 16
 wave = ly // 4
 sub, qx, qy = lx // 4, lx % 4, ly % 4
 lane = sub * 16 + ((qy // 2) * 2 + (qx // 2)) * 4 + (qy % 2) * 2 + (qx % 2)
-nrec = a["n"].view(sc.H, sc.W).clamp(max=256).to(torch.int64)
+nrec = a["n"].view(sc.H, sc.W).clamp(max=depth).to(torch.int64)
 diff = 0
-for k in range(0, 256):
+for k in range(0, depth):
     m = nrec > k
     if not bool(m.any()):
         break

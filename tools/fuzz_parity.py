@@ -54,7 +54,13 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--seconds", type=float, default=600.0)
     ap.add_argument("--heavy", action="store_true", help="dense scenes (overflowing blend logs, long lists) instead of the small ones")
+    ap.add_argument("--fma", action="store_true", help="sweep the second shipped library (libstp_raster_fma.so) against the oracle's fma depth order")
     args = ap.parse_args()
+    if args.fma:
+        from diff_gaussian_rasterization import _C
+        from oracle import oracle as orc
+        _C.use_library("fma")
+        orc.set_flag("ieee_depth", 0)
     rng = random.Random(args.seed)
     t0, done, bad = time.time(), 0, 0
     for i in range(args.cases):
