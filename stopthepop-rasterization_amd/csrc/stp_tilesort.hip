@@ -39,17 +39,35 @@ struct TileSortArgs {
     float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
 };
 
+#ifndef STP_GATHER_ABLATE
+#define STP_GATHER_ABLATE 0 // timing experiments (results WRONG): 1 = no sub-tile masks, 2 = no colour read, 3 = no gpack read (constants), 4 = no entry stores, 5 = no sort network.
+                           // MEASURED (round 4, C2-full, sort stage 0.330 ms, two alternating rounds): without the masks -15 us, without the colour read -22,
+                           // without the entry stores -48 (240 MB: the HBM floor of that part), without the bitonic network -37; the rest is key / list / gpack IO.
+#endif
 __device__ __forceinline__ void write_entry(const TileSortArgs& a, size_t i, int id, int tile)
 {
+#if STP_GATHER_ABLATE == 3
+    const float4 pa = make_float4(1, 0, 0, 1), pb = make_float4(0, 1, 0, 0), pc = make_float4(0, 8.f + id * 1e-9f, 8, 0), pd = make_float4(1, 0, 1, 0.5f);
+    const float3 col = make_float3(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2]);
+#elif STP_GATHER_ABLATE == 2
+    const float4* __restrict__ gp = a.gpack + 4 * (size_t)id;
+    const float4 pa = gp[0], pb = gp[1], pc = gp[2], pd = gp[3];
+    const float3 col = make_float3(pa.x, pa.y, pa.z);
+#else
     const float4* __restrict__ gp = a.gpack + 4 * (size_t)id; // one 64-byte line written by preprocess_kernel
     const float4 pa = gp[0], pb = gp[1], pc = gp[2], pd = gp[3];
     const float3 col = make_float3(a.features[3 * (size_t)id], a.features[3 * (size_t)id + 1], a.features[3 * (size_t)id + 2]);
+#endif
+#if STP_GATHER_ABLATE == 4
+    if (pa.x + pb.y + pc.z + pd.w + col.x == 1.2345e-30f) a.entA[i] = pa;
+    return;
+#endif
     a.entA[i] = pa;
     a.entB[i] = pb;
     a.entC[i] = make_float4(pc.x, pc.y, pc.z, __int_as_float(id));
     a.entD[i] = pd;
     float spare = 0.0f;
-    if (a.cull_mask) spare = __uint_as_float(subtile_mask(a.cull_mask, pd, make_float2(pc.y, pc.z), tile % a.gx, tile / a.gx)); // (stp_device.h)
+    if (a.cull_mask && STP_GATHER_ABLATE != 1) spare = __uint_as_float(subtile_mask(a.cull_mask, pd, make_float2(pc.y, pc.z), tile % a.gx, tile / a.gx)); // (stp_device.h)
     a.entF[i] = make_float4(col.x, col.y, col.z, spare);
 }
 
@@ -123,7 +141,7 @@ __global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArg
             s_key[i] = i < n ? ((keys[i] << 32) | list[i]) : ~0ull;
         }
         __syncthreads();
-        for (int k = 2; k <= m; k <<= 1)
+        for (int k = 2; k <= (STP_GATHER_ABLATE == 5 ? 0 : m); k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int c = tid; c < (m >> 1); c += 256) {
                     const int lo = ((c & ~(j - 1)) << 1) | (c & (j - 1));

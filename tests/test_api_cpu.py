@@ -135,6 +135,14 @@ def test_c_abi_size_and_layout_queries_without_gpu():
     assert cnt.value == 12000 and off.value % 256 == 0
     assert L.stp_geometry_layout(1000, ctypes.byref(s), b"nonsense", ctypes.byref(off), ctypes.byref(cnt)) < 0
     assert b"nonsense" in L.stp_last_error()
+    # blend log of a frame nothing is known about: 192 records + one spare row of 2 bytes per pixel of the tile grid (386 B); a tile-row
+    # window holds its rows' share; the image-side layout of a window starts at the window's first pixel / tile
+    grid_px = ((1920 + 15) // 16) * 16 * ((1080 + 15) // 16) * 16
+    assert _C.blend_log_bytes(1920, 1080) == 386 * grid_px
+    assert _C.blend_log_bytes(1920, 1080, (0, 17)) * 4 == _C.blend_log_bytes(1920, 1080)
+    L.stp_image_layout_rows.argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    assert L.stp_image_layout_rows(1920, 1080, 17, 34, b"ranges", ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == 2 * 120 * 17
+    assert L.stp_image_layout_rows(1920, 1080, 0, 0, b"final_T", ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == 1920 * 1080
     # the viewer's timings text (reference rasterizer_impl.cu:391-399): header, four forward stages, their total
     text = _C.timing_text()
     assert text.startswith("Timings: \n - Preprocess: ") and " - Render: " in text and text.rstrip().endswith("ms")
