@@ -238,11 +238,22 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     dt = time.perf_counter() - t0
     gc.enable()
     stage_ms = {k: v for k, v in _C.timing_read(dev).items() if v >= 0}  # means over the timed region
+    hist = _C.timing_history(dev, capacity=steps)                        # ... and per call (one forward + backward per step), chronological
     _C.timing_enable(False)
-    per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(steps))
+    seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+    per = sorted(seq)
     stats = {"median": round(per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]), 4),
              "min": round(per[0], 4), "max": round(per[-1], 4),
              "how": "intervals between hipEvents recorded on the launch stream after every step of the timed region"} if per else {}
+    if per and len(hist) == steps:
+        # which step was the slowest, and where inside it: its six stage times beside those of the median step (the stage events sit on the launch
+        # stream, so a stall of the launching thread shows up in the stage it interrupted, and `outside_stages` is what no stage interval covers)
+        iw = max(range(steps), key=lambda i: seq[i])
+        im = min(range(steps), key=lambda i: abs(seq[i] - stats["median"]))
+        rec = lambda i: {"index": i, "ms": round(seq[i], 4), "stage_ms": {k: round(v, 4) for k, v in hist[i].items()},
+                         "outside_stages": round(seq[i] - sum(hist[i].values()), 4)}
+        stats["worst_step"] = rec(iw)
+        stats["median_step"] = rec(im)
     return dt, stage_ms, stats, cum
 
 
@@ -303,13 +314,16 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
     fwd_bytes = sum(alg[k] for k in fwd_keys)
     bwd_bytes = sum(alg[k] for k in bwd_keys)
     step_bytes = fwd_bytes + (0 if fwd_only else bwd_bytes)
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    valu_bound = mode in (2, 3)   # the re-sorting render kernels and the replay are VALU-issue / latency bound (PMC: profiles/), not HBM bound
+    roofline = {"bound": "valu" if valu_bound else "hbm", "priced_on": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(prof["hbm_bytes_per_launch"]) if prof else None,
                 "traffic_source": prof_note,
                 "algorithmic_bytes_per_launch": int(alg[dom_key]), "bytes_model": "SURVEY.md section 8(d), verbatim",
                 "design_bytes_per_launch": int(des[dom_key]), "avg_launch_ms": round(dom_ms, 4),
                 "whole_step_frac": round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5),
-                "note": "this kernel is VALU-issue bound, not HBM bound (see \"valu\"); the HBM fraction is reported because the contract asks for it"}
+                "note": ("what bounds this kernel is VALU issue (see \"roofline_valu\" / \"valu\"): achieved / peak / frac here are its HBM figures -- SURVEY 8(d) "
+                         "bytes per launch over the launch duration against 8 TB/s -- which the contract asks for") if valu_bound else
+                        "streaming kernel: achieved / peak / frac are SURVEY 8(d) bytes per launch over the launch duration against 8 TB/s"}
     info = {"P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B, "mode": mode, "order": order,
             "alg": alg, "des": des, "fwd_bytes": fwd_bytes, "bwd_bytes": bwd_bytes, "kname": kname, "dom_ms": dom_ms,
             "prof": prof, "prof_note": prof_note}
@@ -317,8 +331,11 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
 
 
 def hbm_ceilings(dev):
-    """Measured HBM ceilings of THIS box (torch's vectorised elementwise / reduce kernels on 1 GiB fp32 tensors, best of 10):
-    what a streaming kernel can reach here, next to the 8 TB/s spec peak the roofline fractions are priced on."""
+    """Measured HBM ceilings of THIS box in THIS run: the library's own float4 streaming kernels (stp_hbm_probe: read / write / copy, eight
+    16-byte accesses in flight per thread, non-temporal) on 1 GiB, best of 10 over a few grid sizes -- what a streaming kernel can reach
+    here, next to the 8 TB/s spec peak the roofline fractions are priced on (MI355X_MICROARCH.md measures 6.29 TB/s for a copy).  torch's
+    generic kernels on the same buffers are kept as a side object: `sum` is a reduction kernel, not a read ceiling."""
+    from diff_gaussian_rasterization import _C
     n = 1 << 28
     x = torch.ones(n, device=dev); y = torch.empty_like(x)
 
@@ -333,9 +350,18 @@ def hbm_ceilings(dev):
             b = min(b, e0.elapsed_time(e1))
         return b
     gb = n * 4 / 1e9
-    out = {"read_GBps": round(1e3 * gb / best(lambda: x.sum()), 1), "write_GBps": round(1e3 * gb / best(lambda: y.fill_(2.0)), 1),
-           "copy_GBps": round(1e3 * 2 * gb / best(lambda: y.copy_(x)), 1),
-           "how": "torch sum / fill_ / copy_ on 1 GiB fp32, best of 10, this box, this run"}
+    out = {}
+    grids = (2048, 4096, 8192, 16384)
+    for kind, args, factor in (("read", (None, x), 1), ("write", (y, None), 1), ("copy", (y, x), 2)):
+        t = {(g, nt): best(lambda g=g, nt=nt: _C.hbm_probe(kind, args[0], args[1], blocks=g, nontemporal=nt), reps=6) for g in grids for nt in (False, True)}
+        g = min(t, key=t.get)
+        out[f"{kind}_GBps"] = round(1e3 * factor * gb / t[g], 1)
+        out[f"{kind}_config"] = {"blocks": g[0], "nontemporal": g[1]}
+    out["how"] = ("stp_hbm_probe (csrc/stp_hbm_probe.hip): float4 streaming kernels of the library, 1 GiB fp32, best of 6 launches over grids of "
+                  "2048..16384 workgroups x plain / non-temporal accesses, this box, this run; copy counts read + write bytes")
+    out["torch_kernels"] = {"sum_GBps": round(1e3 * gb / best(lambda: x.sum()), 1), "fill_GBps": round(1e3 * gb / best(lambda: y.fill_(2.0)), 1),
+                            "copy_GBps": round(1e3 * 2 * gb / best(lambda: y.copy_(x)), 1),
+                            "how": "torch sum / fill_ / copy_ on the same buffers (the round 2-4 definition of hbm_measured; sum is a reduction kernel, not a read ceiling)"}
     del x, y
     torch.cuda.empty_cache()
     return out
@@ -466,7 +492,7 @@ def other_workloads(dev, steps=10, warmup=3, parity=True):
             ms = 1000.0 * dt / steps
             roof, info = describe(wl, stage_ms, ms)
             out[label] = {"value": round(steps / dt, 3), "unit": "frames/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup,
-                          "step_ms": {k: stats[k] for k in ("median", "min", "max")} if stats else {},
+                          "step_ms": {k: stats[k] for k in ("median", "min", "max", "worst_step", "median_step") if k in stats} if stats else {},
                           "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
                           "P": info["P"], "num_rendered": info["num_rendered"], "blended_pairs": info["blended_pairs"],
                           "resolution": f"{wl.scene.W}x{wl.scene.H}", "passes": "fwd" if wl.fwd_only else "fwd+bwd",

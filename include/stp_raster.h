@@ -180,8 +180,14 @@ size_t stp_image_buffer_size(int width, int height); /* without the optional ble
    STP_LOG_DEPTH=n in the environment fixes the depth.  _rows: of a forward restricted to the tile rows [tile_y0, tile_y1). */
 size_t stp_blend_log_bytes(int width, int height);
 size_t stp_blend_log_bytes_rows(int width, int height, int tile_y0, int tile_y1);
-/* The depth (records per pixel) of the blend log in an image buffer that a recording forward of this process filled. */
+/* The depth (records per pixel) of the blend log in an image buffer a forward filled (0: it recorded none).  Every forward leaves a header in
+   its image and binning buffers (their first 256 bytes: magic, value, ~value), so the buffers are self-contained like the reference's: the
+   library keeps a pointer -> value cache for the buffers of this process and reads the header back (one blocking 16-byte copy) for a pointer it
+   does not know -- a clone, a copy, a buffer of another process.  Negative (STP_ERR_INVALID_ARGUMENT) for a buffer without a valid header. */
 int stp_blend_log_depth(const void* image_buffer);
+/* Bytes of a blend log of `depth` records per pixel (depth <= 0: of the DEEPEST log a forward may carve, 512 records) for the tile rows
+   [tile_y0, tile_y1) (0, 0 = the whole frame): what a memory policy should budget for a frame whose depth it does not know yet. */
+size_t stp_blend_log_bytes_depth(int width, int height, int tile_y0, int tile_y1, int depth);
 
 /* Introspection of the (otherwise opaque) scratch buffers, for parity tests and debugging.
    Fills byte offset and element count of a named sub-array; returns 0 or STP_ERR_INVALID_ARGUMENT.
@@ -192,8 +198,10 @@ int stp_geometry_layout(int P, const StpSettings* settings, const char* name, si
 int stp_binning_layout(int R, const char* name, size_t* offset, size_t* count);
 /* The entry count a binning buffer was carved with by the forward that last used it: num_rendered, or -- for a run-ahead forward, which
    carves and launches before num_rendered is known -- the capacity it guessed (>= num_rendered; the first num_rendered elements of
-   every sub-array are the valid ones).  Pass the result to stp_binning_layout.  R is the fallback for a pointer no forward of this
-   process has carved.  stp_backward does this lookup itself: callers keep passing (buffer, num_rendered) as in the reference. */
+   every sub-array are the valid ones).  Pass the result to stp_binning_layout.  From the library's cache, else from the buffer's own header
+   (see stp_blend_log_depth); negative (STP_ERR_INVALID_ARGUMENT) for a buffer that carries none or was carved for fewer than R entries.
+   stp_backward does this lookup itself -- and refuses such a buffer instead of carving it on a guess: callers keep passing (buffer,
+   num_rendered) as in the reference. */
 int stp_binning_layout_count(const void* binning_buffer, int R);
 /* Forgets the per-device size guesses (tile-list entries of the previous frames of each kind) that the run-ahead forward and the early
    binning request are sized by: the next forward of every kind takes the reference's path again (hand-over in the middle of the frame,
@@ -212,6 +220,9 @@ int stp_image_layout(int width, int height, const char* name, size_t* offset, si
    window's pixel rows and tiles only, element 0 of every sub-array being the window's first pixel / tile (0, 0 = the whole frame).
    The count reported for "blend_log" is that of the default depth (see stp_blend_log_bytes). */
 int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const char* name, size_t* offset, size_t* count);
+/* ... with the blend log at the depth the buffer was really carved with (stp_blend_log_depth(buffer); 0 = the buffer holds no log, the
+   name "blend_log" is then unknown): the count reported for "blend_log" matches the buffer. */
+int stp_image_layout_depth(int width, int height, int tile_y0, int tile_y1, int log_depth, const char* name, size_t* offset, size_t* count);
 
 /* Stage timer, the counterpart of the reference's `Timer` (rasterizer_impl.h:77-147; stages
    "Preprocess","Duplicate","Sort","Render", rasterizer_impl.cu:248) plus "BwdRender","BwdPreprocess".
@@ -223,11 +234,21 @@ int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const
    when an event could not be created or recorded (the timings are then incomplete). */
 void stp_timing_enable(int enabled);
 int stp_timing_read(float* ms6);
+/* Per-call stage times instead of their means: fills ms6[6 * k + stage] for the last n = min(calls since stp_timing_enable(1), 1024,
+   capacity) forward(+backward) calls of the current device in chronological order (-1 = stage not measured in that call) and returns n.
+   What makes a slow step attributable: bench.py puts the worst step's six stage times beside the median step's. */
+int stp_timing_history(float* ms6, int capacity);
 /* The text the reference hands to the SIBR viewer (DebugVisualizationData::timings_text, rasterizer_impl.cu:391-399):
    "Timings: \n - Preprocess: <ms>ms\n - Duplicate: ...\n - Sort: ...\n - Render: ...\n - Total: <sum>ms\n" over the forward
    stages measured since stp_timing_enable(1); measured backward stages follow as two more lines.  Writes at most
    `size` bytes including the terminating NUL and returns the length the full text needs (as snprintf does). */
 size_t stp_timing_text(char* buf, size_t size);
+
+/* Measurement helper (bench.py `hbm_measured`; not part of the reference's interface): one launch of a plain float4 streaming kernel over
+   `bytes` (a multiple of 16) on `stream` -- kind 0: read `src` (dst may be NULL), 1: write `dst`, 2: copy src -> dst, + 4: with non-temporal
+   loads / stores -- with `blocks` workgroups of 256 threads, eight 16-byte accesses in flight per thread.  The caller times it with events on the same stream.  What the box's
+   HBM delivers to the streaming stages of the path, next to the 8 TB/s spec peak. */
+int stp_hbm_probe(int kind, void* dst, const void* src, size_t bytes, int blocks, void* stream);
 
 const char* stp_last_error(void);
 int stp_abi_version(void);

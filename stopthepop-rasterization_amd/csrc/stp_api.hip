@@ -15,6 +15,7 @@
 // first forward of the process.
 #include "stp_internal.h"
 
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +23,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <vector>
 
 namespace stp {
 
@@ -33,13 +35,16 @@ static bool g_timing = false;
 // synchronisation; spans are harvested lazily and averaged (mean over the calls since stp_timing_enable(1)).
 struct StageTimer {
     static constexpr int SETS = 64, EV = 8; // events 0..4: forward stage boundaries, 5..7: backward
-    struct Set { hipEvent_t ev[EV]; bool have[EV]; bool used; };
+    static constexpr int HIST = 1024;       // per-call stage times kept since the last reset (stp_timing_history)
+    struct Set { hipEvent_t ev[EV]; bool have[EV]; bool used; long seq; };
     Set sets[SETS] = {};
     bool created = false;
     int cur = 0;
     double sum[6] = {};
     long cnt[6] = {};
     long failures = 0; // hipEventCreate / Record failures since the last reset (surfaced by stp_timing_read)
+    long calls = 0;    // forwards begun since the last reset
+    float hist[HIST][6]; // stage times of call (seq mod HIST), -1 = not measured
     void ensure()
     {
         if (created) return;
@@ -54,7 +59,7 @@ struct StageTimer {
             if (!(s.have[from[i]] && s.have[to[i]])) continue;
             if (hipEventSynchronize(s.ev[to[i]]) != hipSuccess) continue;
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, s.ev[from[i]], s.ev[to[i]]) == hipSuccess) { sum[i] += ms; cnt[i]++; }
+            if (hipEventElapsedTime(&ms, s.ev[from[i]], s.ev[to[i]]) == hipSuccess) { sum[i] += ms; cnt[i]++; hist[s.seq % HIST][i] = ms; }
         }
         for (auto& h : s.have) h = false;
         s.used = false;
@@ -66,6 +71,8 @@ struct StageTimer {
         cur = (cur + 1) % SETS;
         harvest(sets[cur]); // only blocks if the ring wrapped around unharvested work
         sets[cur].used = true;
+        sets[cur].seq = calls++;
+        for (auto& v : hist[sets[cur].seq % HIST]) v = -1.0f;
     }
     void begin_backward()
     {
@@ -87,6 +94,7 @@ struct StageTimer {
         for (auto& v : sum) v = 0.0;
         for (auto& c : cnt) c = 0;
         failures = 0;
+        calls = 0;
     }
 };
 // One timer per device (its events live on that device; a backward is attributed to the latest forward OF ITS DEVICE), all
@@ -160,6 +168,7 @@ ImageState carve_image(char* base, int W, int H, int ty0, int ty1, int log_depth
     const int gx = (W + TILE - 1) / TILE;
     const int py0 = ty0 * TILE < H ? ty0 * TILE : H, py1 = ty1 * TILE < H ? ty1 * TILE : H;
     const size_t N = (size_t)W * (size_t)(py1 > py0 ? py1 - py0 : 0), T = (size_t)gx * (size_t)(ty1 > ty0 ? ty1 - ty0 : 0);
+    s.header = c.take<uint32_t>(64, &off); note("header", off, 4); // first 256 bytes of the buffer, whatever the frame and the log's depth
     s.final_T = c.take<float>(N, &off); note("final_T", off, N);
     s.n_contrib = c.take<uint32_t>(N, &off); note("n_contrib", off, N);
     s.ranges = c.take<uint2>(T, &off); note("ranges", off, 2 * T);
@@ -195,6 +204,7 @@ BinningState carve_binning(char* base, size_t R, size_t* total, NamedOffset* nam
     size_t off;
     int n = 0;
     auto note = [&](const char* nm, size_t o, size_t cnt) { if (names) names[n] = {nm, o, cnt}; n++; };
+    b.header = c.take<uint32_t>(64, &off); note("header", off, 4);
     b.point_list = c.take<uint32_t>(R, &off); note("point_list", off, R);
     b.point_list_unsorted = c.take<uint32_t>(R, &off); note("point_list_unsorted", off, R);
     b.keys = c.take<uint64_t>(R, &off); note("keys", off, R);
@@ -332,42 +342,84 @@ inline void cpu_relax()
 #endif
 }
 
-// Which entry count a binning buffer was CARVED with.  A run-ahead forward (stp_forward) carves and launches on a capacity before
-// num_rendered is known; the sub-arrays of the buffer then sit at the offsets of that capacity, not of the count stp_forward returns.  The
-// backward and the introspection helpers are handed (pointer, num_rendered), as in the reference: they look the pointer up here
-// (stp_binning_layout_count).  One entry per live buffer address, overwritten whenever a forward carves that address again.
+// Which entry count a binning buffer was CARVED with, and which depth an image buffer's blend log.  A run-ahead forward (stp_forward) carves
+// and launches on a capacity before num_rendered is known; the sub-arrays of the buffer then sit at the offsets of that capacity, not of the
+// count stp_forward returns; and the blend log's depth is chosen per frame.  The backward and the introspection helpers are handed (pointer,
+// num_rendered) only, as in the reference -- whose buffers are self-contained blobs.  Ours are too: every forward writes a HEADER into the
+// buffer itself (device side, no extra launch: duplicate_kernel / frame_init_kernel) --
+//     binning: first 256 bytes  {STP_HEADER_MAGIC_BINNING, capacity, ~capacity, 0}
+//     image:   first 256 bytes  {STP_HEADER_MAGIC_IMAGE, depth of the blend log (0: none), ~depth, 0}
+// -- and the HOST keeps a cache pointer -> value so that the backward of the same process needs no read-back (one entry per buffer address,
+// overwritten whenever a forward carves that address again; least-recently-used entries are dropped in batches).  A pointer the cache does
+// not know -- a buffer that was cloned, copied, moved, or whose entry was dropped -- is looked up in the buffer's own header (one blocking
+// 16-byte copy: the rare path); a buffer without a valid header is REFUSED (STP_ERR_INVALID_ARGUMENT) instead of being carved on a guess.
+struct LayoutCache {
+    struct Entry { uint32_t value; uint64_t tick; };
+    std::unordered_map<const void*, Entry> map;
+    uint64_t tick = 0;
+    static constexpr size_t CAP = 8192;
+    void put(const void* p, uint32_t v)
+    {
+        if (map.size() >= CAP && map.find(p) == map.end()) { // drop the least recently used quarter (forwards whose buffers nobody came back for)
+            std::vector<uint64_t> t; t.reserve(map.size());
+            for (const auto& kv : map) t.push_back(kv.second.tick);
+            std::nth_element(t.begin(), t.begin() + t.size() / 4, t.end());
+            const uint64_t cut = t[t.size() / 4];
+            for (auto it = map.begin(); it != map.end();) it = it->second.tick <= cut ? map.erase(it) : std::next(it);
+        }
+        map[p] = Entry{v, ++tick};
+    }
+    bool get(const void* p, uint32_t* v)
+    {
+        const auto it = map.find(p);
+        if (it == map.end()) return false;
+        it->second.tick = ++tick;
+        *v = it->second.value;
+        return true;
+    }
+};
 std::mutex g_layout_mutex;
-std::unordered_map<const void*, uint32_t> g_layout;
-void remember_layout(const void* binning, uint32_t count)
+LayoutCache g_layout, g_log_depth;
+void remember_layout(const void* binning, uint32_t count) { std::lock_guard<std::mutex> l(g_layout_mutex); g_layout.put(binning, count); }
+void remember_log_depth(const void* image, uint32_t depth) { std::lock_guard<std::mutex> l(g_layout_mutex); g_log_depth.put(image, depth); }
+// the header a forward left in the buffer: 0 and *value on success, else a negative STP_ERR_* (message set)
+int read_buffer_header(const uint32_t* dev_header, uint32_t magic, const char* what, uint32_t* value)
 {
-    std::lock_guard<std::mutex> l(g_layout_mutex);
-    if (g_layout.size() > 8192 && g_layout.find(binning) == g_layout.end()) g_layout.erase(g_layout.begin()); // (thousands of forwards whose buffers nobody reused)
-    g_layout[binning] = count;
+    uint32_t h[4] = {0, 0, 0, 0};
+    if (hipMemcpy(h, dev_header, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return fail(STP_ERR_HIP, std::string("could not read the header of the ") + what + " buffer"); }
+    if (h[0] != magic || h[2] != ~h[1])
+        return fail(STP_ERR_INVALID_ARGUMENT, std::string("the ") + what + " buffer does not carry a header of this library: it was not written by stp_forward (or has been overwritten)");
+    *value = h[1];
+    return 0;
 }
-uint32_t layout_of(const void* binning, uint32_t R)
+// entries the binning buffer was carved for: cache, else the buffer's own header
+int layout_of(const char* binning, uint32_t R, uint32_t* cap)
 {
-    std::lock_guard<std::mutex> l(g_layout_mutex);
-    const auto it = g_layout.find(binning);
-    return it != g_layout.end() && it->second >= R ? it->second : R;
+    {
+        std::lock_guard<std::mutex> l(g_layout_mutex);
+        if (g_layout.get(binning, cap) && *cap >= R) return 0;
+    }
+    if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(binning), STP_HEADER_MAGIC_BINNING, "binning", cap)) return rc;
+    if (*cap < R) return fail(STP_ERR_INVALID_ARGUMENT, "the binning buffer was carved for fewer entries than num_rendered");
+    remember_layout(binning, *cap);
+    return 0;
 }
 
 // run-ahead forward: 0 = never, 1 = whenever a size guess exists, 2 (default) = for SMALL frames only (guess below RUN_AHEAD_AUTO_MAX entries)
 constexpr uint32_t RUN_AHEAD_AUTO_MAX = 1u << 18;
 std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2; }()};
 
-// ... and which depth an image buffer's blend log was carved with (the backward is handed the pointer only)
-std::unordered_map<const void*, uint32_t> g_log_depth;
-void remember_log_depth(const void* image, uint32_t depth)
+// depth the image buffer's blend log was carved with: cache, else the buffer's own header (whose offset does not depend on the depth)
+int log_depth_of(const char* image, uint32_t* depth)
 {
-    std::lock_guard<std::mutex> l(g_layout_mutex);
-    if (g_log_depth.size() > 8192 && g_log_depth.find(image) == g_log_depth.end()) g_log_depth.erase(g_log_depth.begin());
-    g_log_depth[image] = depth;
-}
-uint32_t log_depth_of(const void* image)
-{
-    std::lock_guard<std::mutex> l(g_layout_mutex);
-    const auto it = g_log_depth.find(image);
-    return it != g_log_depth.end() ? it->second : (uint32_t)blend_log_default_depth();
+    {
+        std::lock_guard<std::mutex> l(g_layout_mutex);
+        if (g_log_depth.get(image, depth)) return 0;
+    }
+    if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(image), STP_HEADER_MAGIC_IMAGE, "image", depth)) return rc;
+    if (*depth != 0u && (int)*depth != blend_log_clamp_depth((int)*depth)) return fail(STP_ERR_INVALID_ARGUMENT, "the image buffer's header holds an impossible blend-log depth");
+    remember_log_depth(image, *depth);
+    return 0;
 }
 // Depth of this frame's blend log: the largest blend count per pixel that the recording forwards of this kind reported (slowly forgotten:
 // read_mailbox), + 12.5 % + 4, rounded up to 16 records; a frame nothing is known about gets the default.  STP_LOG_DEPTH=n fixes it.
@@ -454,6 +506,14 @@ size_t stp_blend_log_bytes_rows(int width, int height, int tile_y0, int tile_y1)
 }
 
 size_t stp_blend_log_bytes(int width, int height) { return stp_blend_log_bytes_rows(width, height, 0, 0); }
+size_t stp_blend_log_bytes_depth(int width, int height, int tile_y0, int tile_y1, int depth) // depth <= 0: the deepest log a forward may carve
+{
+    clamp_rows(height, tile_y0, tile_y1);
+    size_t plain = 0, with_log = 0;
+    carve_image(nullptr, width, height, tile_y0, tile_y1, 0, &plain);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, depth > 0 ? blend_log_clamp_depth(depth) : blend_log_clamp_depth(1 << 30), &with_log);
+    return with_log - plain;
+}
 
 static int find_name(const NamedOffset* names, int n, const char* name, size_t* offset, size_t* count)
 {
@@ -492,10 +552,19 @@ void stp_reset_size_guesses(void)
         }
     (void)hipSetDevice(cur);
 }
-int stp_blend_log_depth(const void* image_buffer) { return (int)log_depth_of(image_buffer); }
+int stp_blend_log_depth(const void* image_buffer)
+{
+    if (!image_buffer) return fail(STP_ERR_INVALID_ARGUMENT, "null image buffer");
+    uint32_t d = 0;
+    if (int rc = log_depth_of((const char*)image_buffer, &d)) return rc;
+    return (int)d;
+}
 int stp_binning_layout_count(const void* binning_buffer, int R)
 {
-    return (int)layout_of(binning_buffer, (uint32_t)(R > 0 ? R : 0));
+    if (!binning_buffer) return fail(STP_ERR_INVALID_ARGUMENT, "null binning buffer");
+    uint32_t cap = 0;
+    if (int rc = layout_of((const char*)binning_buffer, (uint32_t)(R > 0 ? R : 0), &cap)) return rc;
+    return (int)cap;
 }
 int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const char* name, size_t* offset, size_t* count)
 {
@@ -507,6 +576,13 @@ int stp_image_layout_rows(int width, int height, int tile_y0, int tile_y1, const
 int stp_image_layout(int width, int height, const char* name, size_t* offset, size_t* count)
 {
     return stp_image_layout_rows(width, height, 0, 0, name, offset, count);
+}
+int stp_image_layout_depth(int width, int height, int tile_y0, int tile_y1, int log_depth, const char* name, size_t* offset, size_t* count)
+{
+    NamedOffset names[16]; int n = 0;
+    clamp_rows(height, tile_y0, tile_y1);
+    carve_image(nullptr, width, height, tile_y0, tile_y1, log_depth > 0 ? blend_log_clamp_depth(log_depth) : 0, nullptr, names, &n);
+    return find_name(names, n, name, offset, count);
 }
 
 void stp_timing_enable(int enabled)
@@ -533,6 +609,19 @@ int stp_timing_read(float* ms6) // the calling thread's current device
         if (t.cnt[i] > 0) ms6[i] = (float)(t.sum[i] / (double)t.cnt[i]);
     if (t.failures > 0) return fail(STP_ERR_HIP, "stage timer: " + std::to_string(t.failures) + " hipEvent create/record call(s) failed; timings are incomplete");
     return 0;
+}
+
+int stp_timing_history(float* ms6, int capacity) // the calling thread's current device
+{
+    if (!ms6 || capacity < 0) return fail(STP_ERR_INVALID_ARGUMENT, "null output");
+    std::lock_guard<std::mutex> l(g_timer_mutex);
+    StageTimer& t = current_timer();
+    if (!t.created) return 0;
+    for (auto& s : t.sets) t.harvest(s);
+    const long n = std::min<long>(std::min<long>(t.calls, StageTimer::HIST), capacity);
+    for (long k = 0; k < n; k++) // chronological: the last n calls
+        std::memcpy(ms6 + 6 * k, t.hist[(t.calls - n + k) % StageTimer::HIST], 6 * sizeof(float));
+    return (int)n;
 }
 
 size_t stp_timing_text(char* buf, size_t size)
@@ -610,7 +699,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
     ImageState img = carve_image(img_ptr, width, height, f.ty0, f.ty1, log_depth, nullptr);
-    if (with_log) remember_log_depth(img_ptr, (uint32_t)log_depth);
+    remember_log_depth(img_ptr, (uint32_t)log_depth); // (+ the buffer's own header, written by frame_init_kernel)
 
     // How the (tile, depth) order is established:
     //   default           device-wide radix sort on the tile bits only (two passes), then the tile's own workgroup sorts its
@@ -731,7 +820,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     auto binning_and_render = [&](const GeometryState& gd, const BinningState& b, int L, uint32_t dup_cap) -> int {
         uint32_t* zero_ptr = nullptr; size_t zero_words = 0; // (the tile-bit sort's histograms / look-back states / block counters: cleared here, once)
         if (!atomic_bin && tile_local_sort) sort_zero_region(b, (size_t)L, &zero_ptr, &zero_words);
-        STP_TRY(launch_duplicate(f, gd, radii, b, atomic_bin ? img.tile_cursor : nullptr, dup_cap, zero_ptr, zero_words, st), "duplicate launch");
+        STP_TRY(launch_duplicate(f, gd, radii, b, atomic_bin ? img.tile_cursor : nullptr, dup_cap, (uint32_t)L, zero_ptr, zero_words, st), "duplicate launch");
         STP_DEBUG_SYNC("duplicate");
         g_timer.mark(2, st);
         if (!colour_started) {
@@ -840,8 +929,12 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
                rotations, cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, cam_pos, tan_fovx, tan_fovy, 0);
     const bool with_inv = requires_depth_along_ray(*settings);
     GeometryState g = carve_geometry(geom_buffer, (size_t)P, with_inv, nullptr);
-    BinningState b = carve_binning(binning_buffer, (size_t)layout_of(binning_buffer, (uint32_t)(R > 0 ? R : 0)), nullptr); // (a run-ahead forward carved it for its capacity)
-    ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, uses_blend_log(*settings) ? (int)log_depth_of(image_buffer) : 0, nullptr);
+    // what the buffers were carved with travels with them (cache of this process, else the buffers' own headers): a buffer that carries none is refused
+    uint32_t bin_cap = 0, log_depth = 0;
+    if (R > 0) { if (int rc = layout_of(binning_buffer, (uint32_t)R, &bin_cap)) return rc; } // (a run-ahead forward carved it for its capacity)
+    if (uses_blend_log(*settings)) { if (int rc = log_depth_of(image_buffer, &log_depth)) return rc; }
+    BinningState b = carve_binning(binning_buffer, (size_t)bin_cap, nullptr);
+    ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, (int)log_depth, nullptr);
     if (!radii) radii = g.internal_radii;
 
     BackwardParams bw;

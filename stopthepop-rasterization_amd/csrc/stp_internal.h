@@ -90,12 +90,14 @@ struct ImageState { // reference ImageState, rasterizer_impl.cu:195-202 (ranges 
     uint32_t* tile_counts; // T
     uint32_t* tile_cursor; // T
     uint32_t* bin_total;   // 2
+    uint32_t* header;      // 4: {STP_HEADER_MAGIC_IMAGE, log_depth, ~log_depth, 0} -- the blend log's depth travels WITH the buffer (stp_api.hip: buffer headers)
     uint32_t* tile_flags; // T   0 = this tile's log is valid, 1 = its log overflowed, 0xFFFFFFFF = the forward recorded no log
     uint32_t* blend_log;  // T * 4 waves * (log_depth + spare) rows * 64 lanes of u16 (only with the blend log)
     int log_depth;        // records per pixel the log holds (0: none)
 };
 
 struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
+    uint32_t* header;      // first 256 bytes of the buffer: {STP_HEADER_MAGIC_BINNING, entries the buffer was carved for, ~that, 0} (stp_api.hip: buffer headers)
     uint32_t* point_list;
     uint32_t* point_list_unsorted;
     uint64_t* keys;
@@ -113,6 +115,7 @@ struct BinningState { // reference BinningState, rasterizer_impl.cu:204-217
     float4* entF;
 };
 
+constexpr uint32_t STP_HEADER_MAGIC_BINNING = 0x42505453u, STP_HEADER_MAGIC_IMAGE = 0x49505453u; // "STPB", "STPI"
 struct NamedOffset { const char* name; size_t offset; size_t count; };
 
 GeometryState carve_geometry(char* base, size_t P, bool with_inv, size_t* total, NamedOffset* names = nullptr, int* n_names = nullptr);
@@ -172,7 +175,7 @@ hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st);
 hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st); // second level of the scan + the hand-over
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t* zero_ptr, size_t zero_words, hipStream_t st); // tile_cursor: nullptr = by point_offsets into the unsorted arrays; cap: slots of a run-ahead launch (0xFFFFFFFF = exact)
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t header_cap, uint32_t* zero_ptr, size_t zero_words, hipStream_t st); // header_cap: entries the buffer was carved for (its header); tile_cursor: nullptr = by point_offsets into the unsorted arrays; cap: slots of a run-ahead launch (0xFFFFFFFF = exact)
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, bool zeroed, hipStream_t st); // zeroed: duplicate_kernel cleared sort_zero_region()

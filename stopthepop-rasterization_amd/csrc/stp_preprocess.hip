@@ -439,6 +439,8 @@ struct DupArgs {
     uint32_t cap;          // slots the arrays hold: a run-ahead forward (stp_api.hip) launches on a capacity, not on num_rendered; 0xFFFFFFFF = exact
     int n_gauss_blocks;    // workgroups that own Gaussians; the DUP_PAD_BLOCKS behind them fill [num_rendered, cap) with padding entries
     int n_pad_blocks;      // DUP_PAD_BLOCKS for a capacity launch, else 0
+    uint32_t* header;      // the binning buffer's header (stp_api.hip: buffer headers), written by the first thread
+    uint32_t header_cap;   // entries the buffer was carved for
     uint32_t* zero_ptr;    // cleared by the DUP_ZERO_BLOCKS workgroups behind those: the tile-bit sort's histograms, look-back states and block
     uint32_t zero_words;   // counters (stp_binning.hip: sort_zero_region), which the library's own driver clears with five separate fill launches
 };
@@ -469,6 +471,7 @@ __device__ __forceinline__ bool duplicate_tile(const DupArgs& a, const DupGaussi
 __global__ void __launch_bounds__(256) duplicate_kernel(const DupArgs a)
 {
 #pragma clang fp contract(off)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.header) { a.header[0] = STP_HEADER_MAGIC_BINNING; a.header[1] = a.header_cap; a.header[2] = ~a.header_cap; a.header[3] = 0u; }
     if ((int)blockIdx.x >= a.n_gauss_blocks + a.n_pad_blocks) {
         uint4* const z = reinterpret_cast<uint4*>(a.zero_ptr); // (256-byte aligned, a multiple of 64 words)
         for (uint32_t i = ((uint32_t)blockIdx.x - (uint32_t)(a.n_gauss_blocks + a.n_pad_blocks)) * 256u + threadIdx.x; i < a.zero_words / 4u; i += (uint32_t)DUP_ZERO_BLOCKS * 256u)
@@ -629,8 +632,8 @@ hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* 
     return hipGetLastError();
 }
 
-hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t* zero_ptr, size_t zero_words,
-                            hipStream_t st)
+hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const int* radii, const BinningState& b, uint32_t* tile_cursor, uint32_t cap, uint32_t header_cap,
+                            uint32_t* zero_ptr, size_t zero_words, hipStream_t st)
 {
     DupArgs a;
     a.P = f.P; a.W = f.W; a.H = f.H; a.gx = f.gx; a.gy = f.gy; a.ty0 = f.ty0; a.ty1 = f.ty1;
@@ -643,6 +646,7 @@ hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const 
     a.n_gauss_blocks = (f.P + 255) / 256;
     a.n_pad_blocks = capped ? DUP_PAD_BLOCKS : 0;
     a.zero_ptr = zero_ptr; a.zero_words = (uint32_t)zero_words;
+    a.header = b.header; a.header_cap = header_cap;
     hipLaunchKernelGGL(duplicate_kernel, dim3(a.n_gauss_blocks + a.n_pad_blocks + (zero_words ? DUP_ZERO_BLOCKS : 0)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
@@ -721,10 +725,12 @@ hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, u
 // words, the tile ranges (reference rasterizer_impl.cu:354) and the tile flags (0 = "this tile's log is valid", all ones =
 // "the forward recorded no log", see carve_image).
 __global__ void __launch_bounds__(256) frame_init_kernel(uint32_t* __restrict__ status, uint2* __restrict__ ranges, uint32_t* __restrict__ tile_flags,
-                                                          uint32_t flag_value, uint32_t* __restrict__ tile_counts, int tile0, int T)
+                                                          uint32_t flag_value, uint32_t* __restrict__ tile_counts, int tile0, int T,
+                                                          uint32_t* __restrict__ header, uint32_t log_depth)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 64) status[i] = 0u;
+    if (i == 0) { header[0] = STP_HEADER_MAGIC_IMAGE; header[1] = log_depth; header[2] = ~log_depth; header[3] = 0u; } // the image buffer describes itself (stp_api.hip: buffer headers)
     if (i < T) { // the tiles of the frame's tile-row window (the arrays hold no others: carve_image)
         ranges[tile0 + i] = make_uint2(0u, 0u);
         tile_flags[tile0 + i] = flag_value;
@@ -736,7 +742,7 @@ hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int 
 {
     const int n = T > 64 ? T : 64;
     hipLaunchKernelGGL(frame_init_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g.status, img.ranges, img.tile_flags, with_log ? 0u : 0xFFFFFFFFu,
-                       tile_counters ? img.tile_counts : nullptr, tile0, T);
+                       tile_counters ? img.tile_counts : nullptr, tile0, T, img.header, (uint32_t)(with_log ? img.log_depth : 0));
     return hipGetLastError();
 }
 

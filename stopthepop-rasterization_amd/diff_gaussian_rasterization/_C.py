@@ -84,6 +84,10 @@ def _load():
     L.stp_timing_enable.restype = None
     L.stp_timing_read.argtypes = [ctypes.POINTER(ctypes.c_float)]
     L.stp_timing_read.restype = ci
+    L.stp_hbm_probe.argtypes = [ci, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ci, ctypes.c_void_p]
+    L.stp_hbm_probe.restype = ci
+    L.stp_timing_history.argtypes = [ctypes.POINTER(ctypes.c_float), ci]
+    L.stp_timing_history.restype = ci
     L.stp_timing_text.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.stp_timing_text.restype = ctypes.c_size_t
     L.stp_binning_layout_count.argtypes = [vp, ci]
@@ -174,16 +178,22 @@ def backward_mode() -> str:
     return _backward_mode
 
 
-def blend_log_bytes(width: int, height: int, tile_rows=None) -> int:
-    """Bytes of the blend log of one forward at this resolution for a frame nothing is known about (386 B per pixel of the 16x16 tile
-    grid; the library's own figure -- later frames of the same kind get the depth their predecessors needed: blend_log_depth).
+def blend_log_bytes(width: int, height: int, tile_rows=None, depth=None) -> int:
+    """Bytes of the blend log of one forward at this resolution.  depth = None: of a frame nothing is known about (386 B per pixel of the
+    16x16 tile grid; later frames of the same kind get the depth their predecessors needed: blend_log_depth); depth = n: of a log of n
+    records per pixel; depth = 0: of the DEEPEST log a forward may carve (what a memory policy has to budget before the forward has run).
     tile_rows = (y0, y1): of a forward restricted to that tile-row window (a rank of a tile-row shard holds its rows' log only)."""
     L = _load()
+    y0, y1 = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
+    if depth is not None:
+        L.stp_blend_log_bytes_depth.argtypes = [ctypes.c_int] * 5
+        L.stp_blend_log_bytes_depth.restype = ctypes.c_size_t
+        return int(L.stp_blend_log_bytes_depth(int(width), int(height), y0, y1, int(depth)))
     if tile_rows is None:
         return int(L.stp_blend_log_bytes(int(width), int(height)))
     L.stp_blend_log_bytes_rows.argtypes = [ctypes.c_int] * 4
     L.stp_blend_log_bytes_rows.restype = ctypes.c_size_t
-    return int(L.stp_blend_log_bytes_rows(int(width), int(height), int(tile_rows[0]), int(tile_rows[1])))
+    return int(L.stp_blend_log_bytes_rows(int(width), int(height), y0, y1))
 
 
 class LogLease:
@@ -193,6 +203,12 @@ class LogLease:
     def __init__(self, index: int, nbytes: int):
         self.index, self.nbytes = index, int(nbytes)
         _log_live[index] = _log_live.get(index, 0) + self.nbytes
+
+    def resize(self, nbytes: int) -> None:
+        """The forward has run: account what its log really takes (the library chooses the depth per frame)."""
+        if self.nbytes:
+            _log_live[self.index] = _log_live.get(self.index, 0) - self.nbytes + int(nbytes)
+            self.nbytes = int(nbytes)
 
     def release(self) -> None:
         if self.nbytes:
@@ -214,7 +230,7 @@ def decide_recording(mode, device, width: int, height: int, tile_rows=None) -> b
     if mode != "auto":
         return mode == "replay"
     idx = _device_index(device)
-    need = blend_log_bytes(width, height, tile_rows)
+    need = blend_log_bytes(width, height, tile_rows, depth=0)   # (the deepest log the forward may carve: its depth is the library's choice)
     pooled = list(_native().pooled_sizes(idx))
     reuse = any(need <= n for n in pooled)   # a pooled buffer takes the new log: no new memory
     return _log_live.get(idx, 0) + sum(pooled) + (0 if reuse else need) <= _log_budget_bytes
@@ -350,6 +366,8 @@ def binning_array(binningBuffer, R, name):
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
     L = _load()
     lay = int(L.stp_binning_layout_count(ctypes.c_void_p(binningBuffer.data_ptr()), int(R))) if int(R) > 0 else 0
+    if lay < 0:
+        _raise_last(lay)
     if L.stp_binning_layout(lay, name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
         raise KeyError(name)
     n = cnt.value // lay * int(R) if lay > 0 else cnt.value
@@ -358,12 +376,14 @@ def binning_array(binningBuffer, R, name):
 
 def image_array(imgBuffer, W, H, name, tile_rows=None):
     """Named view into an image buffer.  tile_rows = (y0, y1): the buffer of a forward restricted to that tile-row window -- it holds the
-    window's pixel rows / tiles only (element 0 = the window's first pixel / tile)."""
+    window's pixel rows / tiles only (element 0 = the window's first pixel / tile).  "blend_log" is reported at the depth the buffer was
+    carved with (its header: blend_log_depth)."""
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
     L = _load()
-    L.stp_image_layout_rows.argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
+    L.stp_image_layout_depth.argtypes = [ctypes.c_int] * 5 + [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     y0, y1 = (0, 0) if tile_rows is None else (int(tile_rows[0]), int(tile_rows[1]))
-    if L.stp_image_layout_rows(int(W), int(H), y0, y1, name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
+    depth = blend_log_depth(imgBuffer) if name == "blend_log" else 0
+    if L.stp_image_layout_depth(int(W), int(H), y0, y1, depth, name.encode(), ctypes.byref(off), ctypes.byref(cnt)) != 0:
         raise KeyError(name)
     return _view(imgBuffer, off.value, cnt.value, _IMG_TYPES[name])
 
@@ -373,7 +393,10 @@ def blend_log_depth(imgBuffer) -> int:
     L = _load()
     L.stp_blend_log_depth.argtypes = [ctypes.c_void_p]
     L.stp_blend_log_depth.restype = ctypes.c_int
-    return int(L.stp_blend_log_depth(ctypes.c_void_p(imgBuffer.data_ptr())))
+    d = int(L.stp_blend_log_depth(ctypes.c_void_p(imgBuffer.data_ptr())))
+    if d < 0:
+        _raise_last(d)
+    return d
 
 
 def set_run_ahead(mode) -> int:
@@ -397,6 +420,31 @@ def reset_size_guesses() -> None:
 
 def timing_enable(flag: bool) -> None:
     _load().stp_timing_enable(int(bool(flag)))
+
+
+def hbm_probe(kind: str, dst, src, blocks: int = 4096, nontemporal: bool = False) -> None:
+    """One launch of the library's float4 streaming kernel (`read` src, `write` dst, `copy` src -> dst) on torch's current stream: the
+    box's HBM ceiling for a plain stream (bench.py `hbm_measured`)."""
+    import torch
+    t = src if src is not None else dst
+    k = {"read": 0, "write": 1, "copy": 2}[kind] + (4 if nontemporal else 0)
+    with _on_device(t.device):
+        rc = _load().stp_hbm_probe(k, None if dst is None else dst.data_ptr(), None if src is None else src.data_ptr(),
+                                   t.numel() * t.element_size(), int(blocks), torch.cuda.current_stream(t.device).cuda_stream)
+    if rc < 0:
+        raise RuntimeError(f"stp_hbm_probe failed ({rc})")
+
+
+def timing_history(device=None, capacity=1024):
+    """Stage times of the last (up to `capacity`) timed calls on `device`, one dict per forward(+backward) in chronological order;
+    a stage that was not measured in a call is missing from its dict."""
+    arr = (ctypes.c_float * (6 * capacity))()
+    with _on_device(device):
+        n = _load().stp_timing_history(arr, capacity)
+    if n < 0:
+        _raise_last(n)
+    names = ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess")
+    return [{nm: float(arr[6 * k + i]) for i, nm in enumerate(names) if arr[6 * k + i] >= 0.0} for k in range(n)]
 
 
 def timing_read(device=None):

@@ -82,6 +82,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         else:
             num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
 
+        if ctx.log_lease is not None:   # the library chose the log's depth for this frame: account what the buffer really holds
+            ctx.log_lease.resize(_C.blend_log_bytes(rs.image_width, rs.image_height, depth=_C.blend_log_depth(imgBuffer)))
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.img_generation = _C.scratch_generation(imgBuffer)

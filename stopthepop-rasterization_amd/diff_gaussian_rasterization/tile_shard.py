@@ -195,6 +195,8 @@ class _ShardedRasterize(torch.autograd.Function):
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
                 rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, sdict, rs.render_depth, rs.debug)
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        if ctx.log_lease is not None:   # the library chose the log's depth for this frame: account what the buffer really holds
+            ctx.log_lease.resize(_C.blend_log_bytes(rs.image_width, rs.image_height, rows, depth=_C.blend_log_depth(imgBuffer)))
         ctx.rs, ctx.sdict, ctx.shard, ctx.num_rendered = rs, sdict, shard, num_rendered
         ctx.img_generation = _C.scratch_generation(imgBuffer)
         ctx.bin_generation = _C.scratch_generation(binningBuffer)

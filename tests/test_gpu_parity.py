@@ -282,10 +282,12 @@ def test_resorting_backward_still_selectable():
 
 
 def test_backward_mode_auto_holds_eight_1080p_forwards_within_a_4GB_log_budget():
-    """A trainer that sums K views before ONE backward holds K blend logs (0.8-1.1 GB each at 1080p, by the log depth).  Mode "auto"
-    records while live + pooled + new log bytes fit the budget and lets the remaining forwards take the re-sorting backward:
-    eight un-backpropagated 1080p forwards under a budget of 3.5 logs keep three logs, and the gradients of the summed loss equal
-    those of eight replayed forwards."""
+    """A trainer that sums K views before ONE backward holds K blend logs (0.6-1.1 GB each at 1080p, by the log depth).  Mode "auto"
+    records while live + pooled + new log bytes fit the budget and lets the remaining forwards take the re-sorting backward.  The depth of a
+    log is the library's choice (per frame, up to 512 records): a forward that has not run yet is budgeted at the DEEPEST log it may carve, a
+    forward that has run is accounted at what its buffer really holds.  Eight un-backpropagated 1080p forwards under a budget of 2.5 deepest
+    logs: some record, some do not, the live bytes never pass the budget, and the gradients of the summed loss equal those of eight replayed
+    forwards."""
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _C
     K = 8
@@ -301,7 +303,9 @@ def test_backward_mode_auto_holds_eight_1080p_forwards_within_a_4GB_log_budget()
     w = t(sc.dL_dout)
     log_bytes = _C.blend_log_bytes(sc.W, sc.H)
     assert 0.5e9 < log_bytes < 1.2e9
-    budget = int(3.5 * log_bytes)
+    deepest = _C.blend_log_bytes(sc.W, sc.H, depth=0)
+    assert 2.5 * log_bytes < deepest < 2.8 * log_bytes and _C.blend_log_bytes(sc.W, sc.H, depth=192) == log_bytes
+    budget = int(2.5 * deepest)
 
     def run(mode, budget):
         _C.clear_scratch_pool(dev)
@@ -310,11 +314,14 @@ def test_backward_mode_auto_holds_eight_1080p_forwards_within_a_4GB_log_budget()
             leaves = [t(sc.means3D, True), torch.zeros(sc.P, 3, device=dev, requires_grad=True), t(sc.opacities, True), t(sc.shs, True),
                       t(sc.scales, True), t(sc.rotations, True)]
             m3, m2, op, sh, scl, rot = leaves
-            total, recorded, peak = 0.0, 0, 0
+            total, recorded, peak, held = 0.0, 0, 0, 0
             for i in range(K):
                 color, _ = rast(m3, m2, op, shs=sh, scales=scl, rotations=rot)
-                recorded += int(getattr(color.grad_fn, "log_lease", None) is not None)   # (the buffer's size follows the scene: the lease says whether a log was recorded)
+                if getattr(color.grad_fn, "log_lease", None) is not None:   # (the lease says whether a log was recorded)
+                    recorded += 1
+                    held += _C.blend_log_bytes(sc.W, sc.H, depth=_C.blend_log_depth(color.grad_fn.saved_tensors[11]))
                 total = total + (color * w).sum() * (1.0 + 0.125 * i)
+                assert _C.live_log_bytes(dev) == held                        # accounted at the depth the buffers were really carved with
                 peak = max(peak, _C.live_log_bytes(dev))
             total.backward()
             assert _C.live_log_bytes(dev) == 0   # every lease went back with its backward
@@ -324,7 +331,8 @@ def test_backward_mode_auto_holds_eight_1080p_forwards_within_a_4GB_log_budget()
             _C.clear_scratch_pool(dev)
 
     g_auto, n_auto, peak_auto = run("auto", budget)
-    assert n_auto == 3 and peak_auto <= budget, (n_auto, peak_auto)   # three logs fit the budget, the fourth does not
+    assert 2 <= n_auto < K and peak_auto <= budget, (n_auto, peak_auto)   # some logs fit the budget, the rest re-sort
+    assert peak_auto + deepest > budget                                   # ... and it stopped because the next one might not have
     g_replay, n_replay, _ = run("replay", None)
     assert n_replay == K
     for a, b in zip(g_auto, g_replay):
@@ -787,3 +795,84 @@ def test_blend_log_depth_follows_the_scene():
     for k in GRAD_KEYS:
         if h[0].grads.get(k) is not None:
             assert _rel(h[2].grads[k], h[0].grads[k]) < 2e-5, k     # replayed == re-sorted
+
+
+def _direct_forward(sc, sd, dev="cuda:0"):
+    """One forward through _C directly (no autograd): the tensors and the six outputs of rasterize_gaussians."""
+    from diff_gaussian_rasterization import _C
+    t = lambda a: torch.tensor(a, device=dev)
+    empty = torch.Tensor([])
+    ten = dict(bg=t(sc.bg), means3D=t(sc.means3D), opac=t(sc.opacities), scales=t(sc.scales), rots=t(sc.rotations), shs=t(sc.shs),
+               view=t(sc.viewmatrix), proj=t(sc.projmatrix), inv=t(sc.inv_viewprojmatrix), cam=t(sc.campos), w=t(sc.dL_dout))
+    out = _C.rasterize_gaussians(ten["bg"], ten["means3D"], empty, ten["opac"], ten["scales"], ten["rots"], sc.scale_modifier, empty, ten["view"],
+                                 ten["proj"], ten["inv"], sc.tanfovx, sc.tanfovy, sc.H, sc.W, ten["shs"], sc.sh_degree, ten["cam"], False, sd, False, False)
+    return ten, out
+
+
+def _direct_backward(sc, sd, ten, out, geom, binning, img):
+    from diff_gaussian_rasterization import _C
+    empty = torch.Tensor([])
+    R, color, radii = out[0], out[1], out[2]
+    return _C.rasterize_gaussians_backward(ten["bg"], ten["means3D"], radii, ten["opac"], empty, ten["scales"], ten["rots"], sc.scale_modifier, empty,
+                                           ten["view"], ten["proj"], ten["inv"], sc.tanfovx, sc.tanfovy, color, ten["w"], ten["shs"], sc.sh_degree,
+                                           ten["cam"], geom, R, binning, img, sd, False)
+
+
+@pytest.mark.parametrize("sd", [settings_dict(**FULL_STP), settings_dict(2, per_pixel=16), settings_dict(0)], ids=["full_stp", "kbuffer16", "global"])
+def test_scratch_buffers_describe_themselves(sd):
+    """The reference hands (buffer, num_rendered) to its backward as self-contained blobs.  Ours carry what they were carved with -- the binning
+    buffer's capacity (a run-ahead forward carves for a guess, not for num_rendered), the blend log's depth (chosen per frame) -- in a header
+    of their own: a CLONE of the buffers, which no cache of the library knows, gives the same gradients as the originals; a buffer whose
+    header is gone is refused instead of being carved on a guess."""
+    from diff_gaussian_rasterization import _C
+    sc = scenes.make_scene(**DENSE)
+    sd = {**sd, "_record_blend_log": True, "_backward_mode": "replay"}
+    _C.reset_size_guesses()
+    before = _C.set_run_ahead(1)
+    try:
+        _, o0 = _direct_forward(sc, sd)                       # the first forward of the kind: exact size, default depth
+        _C.release_scratch(o0[5]); _C.release_scratch(o0[4])
+        for _ in range(2):                                    # the third: run-ahead capacity, depth by the scene
+            ten, out = _direct_forward(sc, sd)
+        R, geom, binning, img = out[0], out[3], out[4], out[5]
+        cap = _C.binning_array(binning, R, "keys").numel()   # (view of the first R entries)
+        assert cap == R
+        assert int(_C._load().stp_binning_layout_count(binning.data_ptr(), R)) == R + R // 8 + 1024
+        ref = _direct_backward(sc, sd, ten, out, geom, binning, img)
+        geom2, binning2, img2 = geom.clone(), binning.clone(), img.clone()
+        assert int(_C._load().stp_binning_layout_count(binning2.data_ptr(), R)) == R + R // 8 + 1024   # read from the clone's own header
+        if sd["sort_settings"]["sort_mode"] in (2, 3):
+            assert _C.blend_log_depth(img2) == _C.blend_log_depth(img) > 0
+        else:
+            assert _C.blend_log_depth(img2) == 0
+        got = _direct_backward(sc, sd, ten, out, geom2, binning2, img2)
+        for a, b in zip(got, ref):
+            if a is not None and b is not None and b.numel():
+                assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        # no header, no backward
+        img3 = img.clone(); img3[:16] = 0
+        if sd["sort_settings"]["sort_mode"] in (2, 3):
+            with pytest.raises(RuntimeError, match="header"):
+                _direct_backward(sc, sd, ten, out, geom2, binning2, img3)
+        bin3 = binning.clone(); bin3[:16] = 0
+        with pytest.raises(RuntimeError, match="header"):
+            _direct_backward(sc, sd, ten, out, geom2, bin3, img2)
+    finally:
+        _C.set_run_ahead(before)
+
+
+def test_stage_timer_keeps_per_call_times():
+    """stp_timing_history: the six stage times of every call since timing_enable(True), in order -- what lets bench.py say WHICH step of a timed
+    region was slow and in which stage."""
+    from diff_gaussian_rasterization import _C
+    sc = scenes.make_scene(**C1)
+    _C.timing_enable(True)
+    for _ in range(5):
+        GpuRun(sc, settings_dict(**FULL_STP), backward=True, warm=False)
+    mean = _C.timing_read()
+    hist = _C.timing_history()
+    _C.timing_enable(False)
+    assert len(hist) == 5
+    for k in ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess"):
+        assert all(h[k] > 0 for h in hist), (k, hist)
+        assert abs(sum(h[k] for h in hist) / 5 - mean[k]) < 1e-3 * max(mean[k], 1.0)
