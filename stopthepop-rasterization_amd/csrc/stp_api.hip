@@ -350,15 +350,17 @@ inline void cpu_relax()
 //     binning: first 256 bytes  {STP_HEADER_MAGIC_BINNING, capacity, ~capacity, 0}
 //     image:   first 256 bytes  {STP_HEADER_MAGIC_IMAGE, depth of the blend log (0: none), ~depth, 0}
 // -- and the HOST keeps a cache pointer -> value so that the backward of the same process needs no read-back (one entry per buffer address,
-// overwritten whenever a forward carves that address again; least-recently-used entries are dropped in batches).  A pointer the cache does
-// not know -- a buffer that was cloned, copied, moved, or whose entry was dropped -- is looked up in the buffer's own header (one blocking
+// overwritten whenever a forward carves that address again; least-recently-used entries are dropped in batches).  An entry also remembers the
+// num_rendered of its forward, and the backward -- which is handed num_rendered -- takes it only if that matches: an address the allocator has
+// re-issued for somebody else's buffer (a clone of another forward's buffers) does not get the previous tenant's layout.  A pointer the cache
+// does not know -- a buffer that was cloned, copied, moved, or whose entry was dropped -- is looked up in the buffer's own header (one blocking
 // 16-byte copy: the rare path); a buffer without a valid header is REFUSED (STP_ERR_INVALID_ARGUMENT) instead of being carved on a guess.
 struct LayoutCache {
-    struct Entry { uint32_t value; uint64_t tick; };
+    struct Entry { uint32_t value; int64_t R; uint64_t tick; };
     std::unordered_map<const void*, Entry> map;
     uint64_t tick = 0;
     static constexpr size_t CAP = 8192;
-    void put(const void* p, uint32_t v)
+    void put(const void* p, uint32_t v, int64_t R)
     {
         if (map.size() >= CAP && map.find(p) == map.end()) { // drop the least recently used quarter (forwards whose buffers nobody came back for)
             std::vector<uint64_t> t; t.reserve(map.size());
@@ -367,12 +369,12 @@ struct LayoutCache {
             const uint64_t cut = t[t.size() / 4];
             for (auto it = map.begin(); it != map.end();) it = it->second.tick <= cut ? map.erase(it) : std::next(it);
         }
-        map[p] = Entry{v, ++tick};
+        map[p] = Entry{v, R, ++tick};
     }
-    bool get(const void* p, uint32_t* v)
+    bool get(const void* p, int64_t R, uint32_t* v) // R < 0: whatever forward carved the address last (introspection right behind a forward)
     {
         const auto it = map.find(p);
-        if (it == map.end()) return false;
+        if (it == map.end() || (R >= 0 && it->second.R != R)) return false;
         it->second.tick = ++tick;
         *v = it->second.value;
         return true;
@@ -380,8 +382,8 @@ struct LayoutCache {
 };
 std::mutex g_layout_mutex;
 LayoutCache g_layout, g_log_depth;
-void remember_layout(const void* binning, uint32_t count) { std::lock_guard<std::mutex> l(g_layout_mutex); g_layout.put(binning, count); }
-void remember_log_depth(const void* image, uint32_t depth) { std::lock_guard<std::mutex> l(g_layout_mutex); g_log_depth.put(image, depth); }
+void remember_layout(const void* binning, uint32_t count, int64_t R) { std::lock_guard<std::mutex> l(g_layout_mutex); g_layout.put(binning, count, R); }
+void remember_log_depth(const void* image, uint32_t depth, int64_t R) { std::lock_guard<std::mutex> l(g_layout_mutex); g_log_depth.put(image, depth, R); }
 // the header a forward left in the buffer: 0 and *value on success, else a negative STP_ERR_* (message set)
 int read_buffer_header(const uint32_t* dev_header, uint32_t magic, const char* what, uint32_t* value)
 {
@@ -397,11 +399,11 @@ int layout_of(const char* binning, uint32_t R, uint32_t* cap)
 {
     {
         std::lock_guard<std::mutex> l(g_layout_mutex);
-        if (g_layout.get(binning, cap) && *cap >= R) return 0;
+        if (g_layout.get(binning, (int64_t)R, cap) && *cap >= R) return 0;
     }
     if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(binning), STP_HEADER_MAGIC_BINNING, "binning", cap)) return rc;
     if (*cap < R) return fail(STP_ERR_INVALID_ARGUMENT, "the binning buffer was carved for fewer entries than num_rendered");
-    remember_layout(binning, *cap);
+    remember_layout(binning, *cap, (int64_t)R);
     return 0;
 }
 
@@ -410,15 +412,15 @@ constexpr uint32_t RUN_AHEAD_AUTO_MAX = 1u << 18;
 std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2; }()};
 
 // depth the image buffer's blend log was carved with: cache, else the buffer's own header (whose offset does not depend on the depth)
-int log_depth_of(const char* image, uint32_t* depth)
+int log_depth_of(const char* image, int64_t R, uint32_t* depth)
 {
     {
         std::lock_guard<std::mutex> l(g_layout_mutex);
-        if (g_log_depth.get(image, depth)) return 0;
+        if (g_log_depth.get(image, R, depth)) return 0;
     }
     if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(image), STP_HEADER_MAGIC_IMAGE, "image", depth)) return rc;
     if (*depth != 0u && (int)*depth != blend_log_clamp_depth((int)*depth)) return fail(STP_ERR_INVALID_ARGUMENT, "the image buffer's header holds an impossible blend-log depth");
-    remember_log_depth(image, *depth);
+    remember_log_depth(image, *depth, R);
     return 0;
 }
 // Depth of this frame's blend log: the largest blend count per pixel that the recording forwards of this kind reported (slowly forgotten:
@@ -556,7 +558,7 @@ int stp_blend_log_depth(const void* image_buffer)
 {
     if (!image_buffer) return fail(STP_ERR_INVALID_ARGUMENT, "null image buffer");
     uint32_t d = 0;
-    if (int rc = log_depth_of((const char*)image_buffer, &d)) return rc;
+    if (int rc = log_depth_of((const char*)image_buffer, -1, &d)) return rc;
     return (int)d;
 }
 int stp_binning_layout_count(const void* binning_buffer, int R)
@@ -699,7 +701,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
     ImageState img = carve_image(img_ptr, width, height, f.ty0, f.ty1, log_depth, nullptr);
-    remember_log_depth(img_ptr, (uint32_t)log_depth); // (+ the buffer's own header, written by frame_init_kernel)
+    // (the buffer's own header is written by frame_init_kernel; the host-side cache entry follows when num_rendered is known)
 
     // How the (tile, depth) order is established:
     //   default           device-wide radix sort on the tile bits only (two passes), then the tile's own workgroup sorts its
@@ -882,7 +884,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         if (int rc = binning_and_render(g_dup, b, (int)cap, cap)) return rc;
         if (int rc = read_mailbox(&R, &wild)) return rc;
         if ((uint32_t)R <= cap && !wild) {
-            remember_layout(bin_ptr, cap);
+            remember_layout(bin_ptr, cap, R);
+            remember_log_depth(img_ptr, (uint32_t)log_depth, R);
             return R;
         }
         // the frame did not fit its guess (or needs the checked reciprocal): once more from duplicate_kernel on, exact this time
@@ -902,7 +905,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     }
     const BinningState b = carve_binning(bin_ptr, (size_t)R, nullptr);
     if (int rc = binning_and_render(g_dup, b, R, 0xFFFFFFFFu)) return rc;
-    if (bin_ptr) remember_layout(bin_ptr, (uint32_t)R);
+    if (bin_ptr) remember_layout(bin_ptr, (uint32_t)R, R);
+    remember_log_depth(img_ptr, (uint32_t)log_depth, R);
     return R;
 }
 
@@ -932,7 +936,7 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     // what the buffers were carved with travels with them (cache of this process, else the buffers' own headers): a buffer that carries none is refused
     uint32_t bin_cap = 0, log_depth = 0;
     if (R > 0) { if (int rc = layout_of(binning_buffer, (uint32_t)R, &bin_cap)) return rc; } // (a run-ahead forward carved it for its capacity)
-    if (uses_blend_log(*settings)) { if (int rc = log_depth_of(image_buffer, &log_depth)) return rc; }
+    if (uses_blend_log(*settings)) { if (int rc = log_depth_of(image_buffer, (int64_t)R, &log_depth)) return rc; }
     BinningState b = carve_binning(binning_buffer, (size_t)bin_cap, nullptr);
     ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, (int)log_depth, nullptr);
     if (!radii) radii = g.internal_radii;
