@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
 //     (two consecutive displaced entries of equal depth) and its payloads are rotated afterwards, in a branch that is almost never entered.
 // What the pop needs of the front entry is fetched when the entry becomes the front, as above; alpha is evaluated again at the pop.
 constexpr int KBR_CAP = 24; // list positions a quad's FIFO may hold in the ring kernel (a round of 16 survivors adds up to 16; not a power of two: 40 KB of LDS = four workgroups per CU)
-template <int WIN> constexpr int kb_ring_waves() { return WIN <= 16 ? 4 : 2; }
+template <int WIN> constexpr int kb_ring_waves() { return WIN <= 16 ? 4 : 3; } // (LDS: 40 KB per workgroup at 16 entries, 48 / 56 KB at 20 / 24)
 template <int WIN> constexpr size_t kb_ring_lds() { return (size_t)WIN * 256 * 8 + 16 * 32 * 4 + 64 * KBR_CAP * 4; }
 
 template <int WIN, int MODE, bool FRCP>
@@ -414,8 +414,10 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     // the ring: logical entry k of my window lives in slot (rh + k) mod WIN of my column
     const uint32_t col = (uint32_t)threadIdx.x * 8u;
     int rn = 0, rh = 0;          // entries in my window, slot of its front
-    float back_d = -FLT_MAX;     // my window's LAST entry (-FLT_MAX: the window is empty): most candidates are decided against it without an LDS access
-    int back_i = 0;
+    float back_d = -FLT_MAX;     // my window's LAST entry (-FLT_MAX: the window is empty) and the one in front of it (-FLT_MAX: none): nine candidates
+    int back_i = 0;              // in ten are placed against these two without an LDS access
+    float back2_d = -FLT_MAX;
+    int back2_i = 0;
     auto wrap = [&](int p) __attribute__((always_inline)) -> int { // p in [0, 2 WIN) -> [0, WIN)
         if constexpr (POW2) return p & (WIN - 1);
         else return p - (p >= WIN ? WIN : 0);
@@ -459,36 +461,45 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
         rh = wrap(rh + (popping ? 1 : 0));
         rn -= popping ? 1 : 0;
         back_d = rn == 0 ? -FLT_MAX : back_d;
+        back2_d = rn <= 1 ? -FLT_MAX : back2_d;
     };
     // insert (depth, cid) into my window where `ins` holds; returns the logical index it took
     auto ring_insert = [&](const bool ins, const float depth, const int cid) __attribute__((always_inline)) -> int {
         int j = rn;                       // the logical index the candidate takes: behind everything, for a start
         int p = wrap(rh + rn);            // ... and its slot
-        float cur_d = back_d;             // the entry in front of it
-        int cur_i = back_i;
-        bool mv = ins && depth < cur_d;   // deeper than the candidate (strictly: a new entry goes behind its equals): it moves up one slot
-        float prev_moved = __builtin_nanf("");
-        bool tie = false;
-        while (__builtin_expect(__builtin_amdgcn_ballot_w64(mv) != 0ull, 0)) {
-            if (mv) {
-                wr(p, cur_d, cur_i);
-                tie = tie || cur_d == prev_moved; // two displaced entries of equal depth: the reference's swap loop leaves them in another order
-                prev_moved = cur_d;
-                p = prev_slot(p);
-                j--;
-                mv = j > 0;
-                if (mv) {
-                    const float2 r = rd(prev_slot(p));
-                    cur_d = r.x; cur_i = __float_as_int(r.y);
-                    mv = depth < cur_d;
+        const bool mv1 = ins && depth < back_d;   // the last entry is deeper than the candidate (strictly: a new entry goes behind its equals): it moves up
+        const bool mv2 = mv1 && depth < back2_d;  // ... and so is the one in front of it
+        bool tie = mv2 && back_d == back2_d;      // two displaced entries of equal depth: the reference's swap loop leaves them in another order
+        if (__builtin_amdgcn_ballot_w64(mv1) != 0ull) {
+            if (mv1) { wr(p, back_d, back_i); p = prev_slot(p); j--; }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(mv2) != 0ull, 0)) { // one step in ten
+                float prev_moved = back2_d;
+                bool mv = mv2;
+                if (mv) { wr(p, back2_d, back2_i); p = prev_slot(p); j--; }
+                float cur_d = -FLT_MAX; int cur_i = 0;
+                mv = mv && j > 0;
+                if (mv) { const float2 r = rd(prev_slot(p)); cur_d = r.x; cur_i = __float_as_int(r.y); mv = depth < cur_d; }
+                while (__builtin_amdgcn_ballot_w64(mv) != 0ull) {
+                    if (mv) {
+                        wr(p, cur_d, cur_i);
+                        tie = tie || cur_d == prev_moved;
+                        prev_moved = cur_d;
+                        p = prev_slot(p);
+                        j--;
+                        mv = j > 0;
+                        if (mv) { const float2 r = rd(prev_slot(p)); cur_d = r.x; cur_i = __float_as_int(r.y); mv = depth < cur_d; }
+                    }
                 }
             }
         }
         if (ins) {
             wr(p, depth, cid);
-            const bool at_back = j == rn;
-            back_d = at_back ? depth : back_d;
-            back_i = at_back ? cid : back_i;
+            // the window's last two entries afterwards: (back, candidate) when nothing moved, (candidate, back) when the last entry did, unchanged otherwise
+            const bool none = !mv1, one = mv1 && !mv2;
+            back2_d = none ? back_d : one ? depth : back2_d;
+            back2_i = none ? back_i : one ? cid : back2_i;
+            back_d = none ? depth : back_d;
+            back_i = none ? cid : back_i;
             rn++;
         }
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(tie) != 0ull, 0)) {
@@ -507,6 +518,7 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
                     k = e + 1;
                 }
                 back_i = __float_as_int(rd(wrap(rh + rn - 1)).y);
+                back2_i = __float_as_int(rd(wrap(rh + rn - 2)).y); // (a tie displaced at least two entries: rn >= 3)
             }
         }
         return j;
@@ -700,6 +712,8 @@ hipError_t launch_kbuffer_wave(int mode, const FrameParams& f, const RenderArgs&
         if (w <= 8) STP_KBR(8);
         if (w <= 12) STP_KBR(12);
         if (w <= 16) STP_KBR(16);
+        if (w <= 20) STP_KBR(20);
+        STP_KBR(24);
     }
     if (w <= 8) STP_KBW(8);
     if (w <= 12) STP_KBW(12);
