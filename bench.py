@@ -391,9 +391,53 @@ def product_frame(wl):
     R = int(o1[0])
     keys = _C.binning_array(o1[4], R, "keys").cpu().numpy().view(np.uint64) if R else np.zeros(0, np.uint64)
     plist = _C.binning_array(o1[4], R, "point_list").cpu().numpy().view(np.uint32) if R else np.zeros(0, np.uint32)
+    sc = wl.scene
+    # what explains a moved pixel (oracle/explain.py): state both sides share bit for bit + the product's final transmittance
+    state = {"W": sc.W, "H": sc.H, "point_list": plist,
+             "ranges": _C.image_array(o1[5], sc.W, sc.H, "ranges").cpu().numpy().view(np.uint32).reshape(-1),
+             "conic_opacity": _C.geometry_array(o1[3], sc.P, wl.sdict, "conic_opacity").cpu().numpy().reshape(-1),
+             "means2D": _C.geometry_array(o1[3], sc.P, wl.sdict, "means2D").cpu().numpy().reshape(-1),
+             "final_T": _C.image_array(o1[5], sc.W, sc.H, "final_T").cpu().numpy().reshape(-1),
+             "cull_4x4": bool(wl.sdict["culling_settings"]["hierarchical_4x4_culling"]) and int(wl.sdict["sort_settings"]["sort_mode"]) == 3}
     _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
     del o1
-    return {"color": color, "grads": grads, "num_rendered": R, "keys": keys, "point_list": plist}
+    return {"color": color, "grads": grads, "num_rendered": R, "keys": keys, "point_list": plist, "state": state}
+
+
+def explain_differences(prod, other_color, other_final_T, other_grads=None, y0=0, y1=None):
+    """The residual of a parity record, explained or not (oracle/explain.py: checker-side code): every pixel that moved by more than 2e-6 must
+    have an entry of its tile list whose alpha -- fp32 exponent, exponential in double -- sits within 6e-7 of 1/255 (per pixel or, with 4x4
+    culling, at its sub-tile's point of maximum contribution), or a final transmittance within 1e-6 of 1e-4; every Gaussian whose gradient
+    is off by more than 1e-4 must be blended at such a pixel.  y0 / y1: pixel rows the comparison covers."""
+    from oracle import explain
+    st = prod["state"]
+    W, H = st["W"], st["H"]
+    y1 = H if y1 is None else y1
+    d = np.abs(np.asarray(prod["color"], np.float64)[:, y0:y1] - np.asarray(other_color, np.float64)[:, y0:y1])
+    moved = np.zeros((H, W), bool)
+    moved[y0:y1] = (d > 2e-6).any(axis=0)
+    ex = explain.explain_moved_pixels(moved, W=W, H=H, ranges=st["ranges"], point_list=st["point_list"], conic_opacity=st["conic_opacity"],
+                                      means2D=st["means2D"], final_T_a=st["final_T"], final_T_b=other_final_T, cull_4x4=st["cull_4x4"])
+    out = {"pixels_moved_gt_2e-6": ex["pixels"], "explained": f"{ex['explained']}/{ex['pixels']}", "by": {k: v for k, v in ex["by"].items() if v},
+           "criterion": "an entry's alpha (fp32 exponent, exp in double) within 6e-7 of 1/255 at the pixel or at its 4x4 sub-tile's culling point, or a final T within 1e-6 of 1e-4"}
+    if ex["unexplained"]:
+        out["unexplained_pixels"] = ex["unexplained"][:8]
+    if other_grads is not None and prod.get("grads") is not None:
+        per_g = None
+        for k, a in prod["grads"].items():
+            b = other_grads.get(k)
+            if a is None or b is None or np.size(b) == 0:
+                continue
+            a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+            if k == "dL_dmeans2D":
+                a, b = a[:, :2], b[:, :2]
+            e = np.abs(a - b).reshape(a.shape[0], -1).max(axis=1) / max(float(np.max(np.abs(b))), 1e-30)
+            per_g = e if per_g is None else np.maximum(per_g, e)
+        if per_g is not None:
+            over = np.nonzero(per_g > 1e-4)[0]
+            out["gaussians_over_1e-4_explained"] = f"{sum(int(i) in ex['gaussians'] for i in over)}/{over.size}"
+    return out
+
 
 
 class ReferenceFrame:
@@ -410,6 +454,7 @@ class ReferenceFrame:
         self.keys = rf.array("keys").view(np.uint64) if self.num_rendered else np.zeros(0, np.uint64)
         self.point_list = rf.array("point_list").view(np.uint32) if self.num_rendered else np.zeros(0, np.uint32)
         self.grads = None if fwd_only else rf.backward(scene.dL_dout)
+        self.final_T = rf.array("final_T").reshape(-1)
         self.rf = rf
 
     def compare(self, prod):
@@ -422,6 +467,11 @@ class ReferenceFrame:
         rec.update(_img_err(prod["color"], self.color))
         if prod["grads"] is not None and self.grads is not None:
             rec.update(_grad_err(prod["grads"], self.grads))
+        if rec["num_rendered_equal"] and rec.get("list_bit_equal") and (rec["pixels_moved_gt_2e-6"] or rec.get("gaussians_over_1e-4")):
+            try:   # (only meaningful when both sides walk the same lists)
+                rec["residual"] = explain_differences(prod, self.color, self.final_T, self.grads)
+            except Exception as ex:
+                rec["residual"] = {"error": repr(ex)[:200]}
         if self.note:
             rec["note"] = self.note
         return rec
@@ -833,9 +883,12 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
                       "fma_depth_build is the second shipped library",
            "window": f"tile rows {y0}..{y0 + nrows - 1} of {gy} of the timed frame",
            **_img_err(img_p, img_o)}
+    gw = None
     if not fwd_only:
         (cw * w_img).sum().backward()
-        par.update(_grad_err(grab(), ograds))
+        gw = grab()
+        par.update(_grad_err(gw, ograds))
+    ofr_final_T = ofr.array("final_T").reshape(-1) if (par["pixels_moved_gt_2e-6"] or par.get("gaussians_over_1e-4")) else None
     ofr.free()
     out["parity"] = par
     # the reference itself on this GPU: whole frame, both builds when present; the default library and the second shipped one
@@ -843,6 +896,16 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
         from oracle import reference as ref
         from diff_gaussian_rasterization import _C
         prod = product_frame(wl)
+        if ofr_final_T is not None:   # the oracle window's residual, explained from the whole frame's shared state
+            try:
+                full = np.array(prod["color"], copy=True)
+                full[:, sl] = img_p            # (the window run's pixels, compared with the oracle's)
+                ocol = np.array(prod["color"], copy=True)
+                ocol[:, sl] = img_o
+                par["residual"] = explain_differences({**prod, "color": full, "grads": gw}, ocol, ofr_final_T if ofr_final_T.size == scene.W * scene.H else None,
+                                                      ograds, y0=sl.start, y1=sl.stop)
+            except Exception as ex:
+                par["residual"] = {"error": repr(ex)[:200]}
         for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
             if not ref.available(variant):
                 continue
