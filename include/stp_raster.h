@@ -147,7 +147,10 @@ int stp_backward(int P, int D, int M, int R,
    pack / unpack copy on either side.  (The padded 64-byte record is what a single GPU wants: one line, one atomic request per flush.)
    phases bit 3 (value 8, with bit 1) = the per-Gaussian half leaves grad_records ZERO-FILLED again: it reads every record the render
    half can have written (those of the visible Gaussians) and clears it behind the read, so that a caller who keeps the buffer between
-   steps never zero-fills it after the first time (the fill is 64 B per Gaussian per step otherwise: 24 us at 1M, 0.14 ms at 6M). */
+   steps never zero-fills it after the first time (the fill is 64 B per Gaussian per step otherwise: 24 us at 1M, 0.14 ms at 6M).
+   phases bits 8-15 = K, bits 16-23 = k (with bit 1 only): the per-Gaussian half on chunk k of K equal ranges of Gaussian ids (ranges of
+   256-Gaussian blocks).  Gaussians are independent there, so a tile-row shard all-reduces its records in K pieces and runs chunk k as soon as
+   piece k has arrived, while piece k + 1 is still on the links (tile_shard.py).  K <= 1: all Gaussians. */
 int stp_backward_phases(int phases, int P, int D, int M, int R,
                         const float* background, int width, int height,
                         const StpSettings* settings,

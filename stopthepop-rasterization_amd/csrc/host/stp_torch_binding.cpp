@@ -258,7 +258,8 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
                              const torch::Tensor& inv_viewprojmatrix, const float tan_fovx, const float tan_fovy, const torch::Tensor& pixel_colors,
                              const torch::Tensor& dL_dout_color, const torch::Tensor& sh, const int degree, const torch::Tensor& campos,
                              const torch::Tensor& geomBuffer, const int R, const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer,
-                             const py::dict& settings, const bool debug, const bool record_log, const int phases, const c10::optional<torch::Tensor>& partial)
+                             const py::dict& settings, const bool debug, const bool record_log, const int phases, const c10::optional<torch::Tensor>& partial,
+                             const c10::optional<std::vector<torch::Tensor>>& outputs)
 {
     need_library();
     TORCH_CHECK(means3D.is_cuda(), "diff_gaussian_rasterization (MI355X build) needs tensors on a GPU device; there is no CPU path in the product");
@@ -288,7 +289,12 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
     TORCH_CHECK(records.dim() == 2 && records.size(0) == P && records.size(1) == rec_floats && records.scalar_type() == torch::kFloat32 &&
                     records.is_contiguous(), "partial must be a contiguous float32 (P,", rec_floats, ") tensor");
     torch::Tensor dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations;
-    if (phases & 2) {
+    if ((phases & 2) && outputs.has_value()) {
+        // a chunked per-Gaussian half (phases bits 8-23): the later chunks write into the tensors the first one allocated
+        TORCH_CHECK(outputs->size() == 8, "outputs: the eight gradient tensors of an earlier chunk");
+        dL_dmeans2D = (*outputs)[0]; dL_dcolors = (*outputs)[1]; dL_dopacity = (*outputs)[2]; dL_dmeans3D = (*outputs)[3];
+        dL_dcov3D = (*outputs)[4]; dL_dsh = (*outputs)[5]; dL_dscales = (*outputs)[6]; dL_drotations = (*outputs)[7];
+    } else if (phases & 2) {
         // the per-Gaussian half writes every row of its outputs (zeros for invisible Gaussians): no zero-fill needed,
         // except for the scale/rotation gradients when a precomputed covariance is used (then they are not touched)
         const bool have_scales = scales.numel() != 0;

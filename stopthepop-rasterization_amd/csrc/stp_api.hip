@@ -945,6 +945,8 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     bw.pixel_colors = pixel_colors; bw.dL_dpix = dL_dpix; bw.dL_dmean2D = dL_dmean2D; bw.grad_rec = grad_records;
     bw.grad_stride = (phases & 4) ? STP_GRAD_RECORD_USED : STP_GRAD_RECORD_FLOATS;
     bw.clear_rec = (phases & 8) ? 1 : 0;
+    bw.chunks = (phases >> 8) & 0xFF; bw.chunk = (phases >> 16) & 0xFF; // per-Gaussian half by id range (see stp_raster.h)
+    if (bw.chunks > 1 && (bw.chunk >= bw.chunks || (phases & 1))) return fail(STP_ERR_INVALID_ARGUMENT, "chunked per-Gaussian half: chunk index out of range, or combined with the render half");
     bw.dL_dopacity = dL_dopacity; bw.dL_dcolor = dL_dcolor; bw.dL_dmean3D = dL_dmean3D; bw.dL_dcov3D = dL_dcov3D; bw.dL_dsh = dL_dsh;
     bw.dL_dscale = dL_dscale; bw.dL_drot = dL_drot;
 

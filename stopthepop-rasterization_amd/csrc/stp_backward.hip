@@ -33,6 +33,7 @@ struct BwdPreArgs {
     const float* grad_rec; // P x grad_stride: sums of the render half (layout: stp_raster.h, stp_backward)
     int grad_stride;       // 16 (one line per Gaussian, two 16-byte loads) or 9 (compact records of a tile-row shard)
     int clear_rec;         // leave every record read zero-filled again (phases bit 3): the caller's buffer is ready for the next backward
+    int block0;            // first 256-Gaussian block of this launch (the grid covers a range of blocks: stp_backward_phases, chunked per-Gaussian half)
     float* dL_dmean2D;     // P x 3  (out)
     float* dL_dopacity;    // P      (out)
     float* dL_dcolor;      // P x 3  (out)
@@ -291,7 +292,7 @@ __global__ void __launch_bounds__(256) preprocess_backward_kernel(const BwdPreAr
 {
     extern __shared__ float s_rows[]; // [256][3M + 1]
     const int tid = (int)threadIdx.x;
-    const int base = (int)blockIdx.x * 256;
+    const int base = ((int)blockIdx.x + a.block0) * 256;
     const int idx = base + tid;
     const int rows = min(256, a.P - base);
     const int row_len = 3 * a.M, row_stride = row_len + 1;
@@ -374,7 +375,15 @@ hipError_t launch_preprocess_backward(const FrameParams& f, const GeometryState&
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(preprocess_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(preprocess_backward_kernel, dim3((f.P + 255) / 256), dim3(256), lds, st, a);
+    const int n_blocks = (f.P + 255) / 256;
+    int b0 = 0, b1 = n_blocks;
+    if (bw.chunks > 1) { // Gaussians are independent in this half: a tile-row shard runs it on the id range whose records have been all-reduced already
+        b0 = (int)((long long)n_blocks * bw.chunk / bw.chunks);
+        b1 = (int)((long long)n_blocks * (bw.chunk + 1) / bw.chunks);
+    }
+    a.block0 = b0;
+    if (b1 <= b0) return hipSuccess;
+    hipLaunchKernelGGL(preprocess_backward_kernel, dim3(b1 - b0), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 

@@ -158,6 +158,7 @@ struct BackwardParams {
     float* grad_rec;    // P x grad_stride: written by the render half, read by the per-Gaussian half
     int grad_stride;    // STP_GRAD_RECORD_FLOATS, or STP_GRAD_RECORD_USED with phases bit 2 (compact records)
     int clear_rec;      // phases bit 3: the per-Gaussian half zero-fills the records again
+    int chunk, chunks;  // the per-Gaussian half on chunk `chunk` of `chunks` equal ranges of 256-Gaussian blocks (chunks <= 1: all Gaussians)
     float* dL_dmean2D;  // outputs of the per-Gaussian half from here on
     float* dL_dopacity;
     float* dL_dcolor;

@@ -309,18 +309,25 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 def rasterize_gaussians_backward(background, means3D, radii, opacities, colors, scales, rotations, scale_modifier,
                                  cov3D_precomp, viewmatrix, projmatrix, inv_viewprojmatrix, tan_fovx, tan_fovy,
                                  pixel_colors, dL_dout_color, sh, degree, campos, geomBuffer, R, binningBuffer,
-                                 imageBuffer, settings_dict, debug, phases=3, partial=None):
+                                 imageBuffer, settings_dict, debug, phases=3, partial=None, chunk=None, outputs=None):
     """== RasterizeGaussiansBackwardCUDA (reference rasterize_points.cu:140-232).
     Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations).
 
     Extension for tile-row sharding (not in the reference): phases=1 runs only the render half and
     returns its per-Gaussian partial sums as the library's (P,16) gradient records (stp_raster.h);
     phases=2 takes the records (after the caller's all-reduce) as `partial` and runs the preprocess half.
-    Adding 4 to either selects COMPACT records, (P,9) with no padding: the tensor that is all-reduced as it is."""
+    Adding 4 to either selects COMPACT records, (P,9) with no padding: the tensor that is all-reduced as it is.
+    chunk = (k, K) with phases=2: the per-Gaussian half on chunk k of K equal ranges of Gaussian ids (the shard all-reduces the records in
+    K pieces and runs chunk k as soon as piece k has arrived); outputs = the tuple an earlier chunk returned (every chunk writes its rows)."""
+    if chunk is not None:
+        k, K = int(chunk[0]), int(chunk[1])
+        if not (0 <= k < K <= 255) or (int(phases) & 1):
+            raise ValueError("chunk = (k, K) with 0 <= k < K <= 255, per-Gaussian half only")
+        phases = int(phases) | (K << 8) | (k << 16)
     out = (_host or _native()).rasterize_gaussians_backward(
         background, means3D, radii, opacities, colors, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix,
         inv_viewprojmatrix, tan_fovx, tan_fovy, pixel_colors, dL_dout_color, sh, int(degree), campos, geomBuffer, int(R), binningBuffer,
-        imageBuffer, settings_dict, bool(debug), _records_log(settings_dict), int(phases), partial)
+        imageBuffer, settings_dict, bool(debug), _records_log(settings_dict), int(phases), partial, None if outputs is None else list(outputs))
     return out[0] if (int(phases) & 3) == 1 else tuple(out)
 
 

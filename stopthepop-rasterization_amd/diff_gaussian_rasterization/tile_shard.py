@@ -138,6 +138,14 @@ def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, 
 
 
 RECORD_USED = 9  # floats of a gradient record that carry data (include/stp_raster.h, stp_backward)
+RECORD_CHUNKS = 2  # pieces the record all-reduce is pipelined in against the per-Gaussian half of the backward (_ShardedRasterize.backward)
+
+
+def record_chunk_bounds(P: int, K: int) -> List[int]:
+    """Row bounds of the K id ranges the library's chunked per-Gaussian half works on (stp_backward_phases: equal ranges of 256-Gaussian
+    blocks): chunk k = rows [bounds[k], bounds[k + 1])."""
+    n_blocks = (P + 255) // 256
+    return [min(P, 256 * (n_blocks * k // K)) for k in range(K)] + [P]
 
 
 def pack_partials(dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors) -> torch.Tensor:
@@ -232,13 +240,27 @@ class _ShardedRasterize(torch.autograd.Function):
         # over the ranks AS IT IS: 36 bytes per Gaussian on the wire, no pack / unpack pass on either side (rounds 1-3 sliced the used
         # columns out of the padded (P, 16) records and copied them back: two strided 36 MB copies per step at C2).
         records = _C.rasterize_gaussians_backward(*args, phases=1 | 4)
-        if _host_staged(dist) and records.is_cuda:
+        # The exchange, taken off the critical path as far as the data flow allows.  A Gaussian's record is complete only when EVERY tile of the
+        # rank has been replayed (any tile may hold any Gaussian), so nothing of the all-reduce can start before the render half has ended; but
+        # the per-Gaussian half is independent per Gaussian: the records are summed in K pieces by id range (asynchronous collectives on RCCL's
+        # own stream) and the per-Gaussian half runs on range k as soon as piece k has arrived, while piece k + 1 is still on the links.
+        K = RECORD_CHUNKS if records.shape[0] >= 256 * RECORD_CHUNKS else 1
+        if _host_staged(dist) and records.is_cuda:   # (gloo: host memory only)
             host = records.cpu()
             dist.all_reduce(host)
             records = host.to(records.device)
+            K = 1
+        if K == 1:
+            if not (_host_staged(dist) and records.is_cuda):
+                dist.all_reduce(records)
+            out = _C.rasterize_gaussians_backward(*args, phases=2 | 4, partial=records)
         else:
-            dist.all_reduce(records)
-        out = _C.rasterize_gaussians_backward(*args, phases=2 | 4, partial=records)
+            bounds = record_chunk_bounds(records.shape[0], K)
+            works = [dist.all_reduce(records[bounds[k]:bounds[k + 1]], async_op=True) for k in range(K)]   # (row ranges of a contiguous (P, 9) tensor)
+            out = None
+            for k in range(K):
+                works[k].wait()   # (the current stream waits for piece k; the host does not)
+                out = _C.rasterize_gaussians_backward(*args, phases=2 | 4, partial=records, chunk=(k, K), outputs=out)
         _C.release_scratch(imgBuffer); _C.release_scratch(binningBuffer)
         if ctx.log_lease is not None:
             ctx.log_lease.release()

@@ -871,3 +871,31 @@ def test_stage_timer_keeps_per_call_times():
     for k in ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess"):
         assert all(h[k] > 0 for h in hist), (k, hist)
         assert abs(sum(h[k] for h in hist) / 5 - mean[k]) < 1e-3 * max(mean[k], 1.0)
+
+
+def test_per_gaussian_half_by_id_range():
+    """stp_backward_phases, phases bits 8-23: the per-Gaussian half of the backward on chunk k of K id ranges -- what lets a tile-row shard run it
+    on the records that have already been all-reduced while the rest is still on the links (tile_shard.py).  Gaussians are independent in that
+    half: K chunks into shared output tensors are bit-identical to one launch, whatever K."""
+    from diff_gaussian_rasterization import _C, tile_shard
+    sc = scenes.make_scene(**DENSE)
+    sd = {**settings_dict(**FULL_STP), "_record_blend_log": True, "_backward_mode": "replay"}
+    ten, out = _direct_forward(sc, sd)
+    empty = torch.Tensor([])
+    args = (ten["bg"], ten["means3D"], out[2], ten["opac"], empty, ten["scales"], ten["rots"], sc.scale_modifier, empty, ten["view"], ten["proj"], ten["inv"],
+            sc.tanfovx, sc.tanfovy, out[1], ten["w"], ten["shs"], sc.sh_degree, ten["cam"], out[3], out[0], out[4], out[5], sd, False)
+    records = _C.rasterize_gaussians_backward(*args, phases=1 | 4)
+    assert records.shape == (sc.P, 9)
+    whole = _C.rasterize_gaussians_backward(*args, phases=2 | 4, partial=records.clone())
+    for K in (2, 3, 7):
+        b = tile_shard.record_chunk_bounds(sc.P, K)
+        assert b[0] == 0 and b[-1] == sc.P and all(x % 256 == 0 for x in b[:-1]) and sorted(b) == b
+        got = None
+        for k in range(K):
+            piece = torch.zeros_like(records)            # only piece k has "arrived": the other rows are not read by chunk k
+            piece[b[k]:b[k + 1]] = records[b[k]:b[k + 1]]
+            got = _C.rasterize_gaussians_backward(*args, phases=2 | 4, partial=piece, chunk=(k, K), outputs=got)
+        for a, w in zip(got, whole):
+            assert torch.equal(a, w)
+    with pytest.raises(RuntimeError):
+        _C.rasterize_gaussians_backward(*args, phases=2 | 4 | (2 << 8) | (5 << 16), partial=records)   # chunk 5 of 2
