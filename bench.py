@@ -239,6 +239,7 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
     gc.enable()
     stage_ms = {k: v for k, v in _C.timing_read(dev).items() if v >= 0}  # means over the timed region
     hist = _C.timing_history(dev, capacity=steps)                        # ... and per call (one forward + backward per step), chronological
+    hist_host = _C.timing_history(dev, capacity=steps, host=True)        # ... and the launching thread's own time inside each stage
     _C.timing_enable(False)
     seq = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     per = sorted(seq)
@@ -251,9 +252,13 @@ def timed_region(wl, steps, warmup, prewarm_seconds, barrier, per_step=False):
         iw = max(range(steps), key=lambda i: seq[i])
         im = min(range(steps), key=lambda i: abs(seq[i] - stats["median"]))
         rec = lambda i: {"index": i, "ms": round(seq[i], 4), "stage_ms": {k: round(v, 4) for k, v in hist[i].items()},
-                         "outside_stages": round(seq[i] - sum(hist[i].values()), 4)}
+                         "outside_stages": round(seq[i] - sum(hist[i].values()), 4),
+                         "host_ms_in_stage": {k: round(v, 4) for k, v in hist_host[i].items()} if len(hist_host) == steps else None}
         stats["worst_step"] = rec(iw)
         stats["median_step"] = rec(im)
+        stats["reading"] = ("stage_ms = GPU interval between the stage's events on the launch stream; host_ms_in_stage = the launching thread's own time between "
+                            "recording them (microseconds when the launches are asynchronous).  A stage that is long in BOTH was waiting for its launches: a late host "
+                            "(descheduled thread, blocking driver call), not a slow kernel")
     return dt, stage_ms, stats, cum
 
 

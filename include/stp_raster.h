@@ -241,6 +241,10 @@ int stp_timing_read(float* ms6);
    capacity) forward(+backward) calls of the current device in chronological order (-1 = stage not measured in that call) and returns n.
    What makes a slow step attributable: bench.py puts the worst step's six stage times beside the median step's. */
 int stp_timing_history(float* ms6, int capacity);
+/* The same for the HOST: milliseconds the launching thread spent between recording a stage's two events (normally microseconds: launches are
+   asynchronous).  A stage whose GPU interval is long while its kernels are not was waiting for a launch: the host figure tells a late host --
+   a descheduled thread, a blocking driver call -- from a slow kernel. */
+int stp_timing_history_host(float* ms6, int capacity);
 /* The text the reference hands to the SIBR viewer (DebugVisualizationData::timings_text, rasterizer_impl.cu:391-399):
    "Timings: \n - Preprocess: <ms>ms\n - Duplicate: ...\n - Sort: ...\n - Render: ...\n - Total: <sum>ms\n" over the forward
    stages measured since stp_timing_enable(1); measured backward stages follow as two more lines.  Writes at most

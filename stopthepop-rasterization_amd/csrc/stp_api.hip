@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,7 +37,7 @@ static bool g_timing = false;
 struct StageTimer {
     static constexpr int SETS = 64, EV = 8; // events 0..4: forward stage boundaries, 5..7: backward
     static constexpr int HIST = 1024;       // per-call stage times kept since the last reset (stp_timing_history)
-    struct Set { hipEvent_t ev[EV]; bool have[EV]; bool used; long seq; };
+    struct Set { hipEvent_t ev[EV]; bool have[EV]; bool used; long seq; std::chrono::steady_clock::time_point host[EV]; };
     Set sets[SETS] = {};
     bool created = false;
     int cur = 0;
@@ -45,6 +46,7 @@ struct StageTimer {
     long failures = 0; // hipEventCreate / Record failures since the last reset (surfaced by stp_timing_read)
     long calls = 0;    // forwards begun since the last reset
     float hist[HIST][6]; // stage times of call (seq mod HIST), -1 = not measured
+    float hist_host[HIST][6]; // ... and the HOST time between recording the stage's two events (the launching thread's own time in that part of the call)
     void ensure()
     {
         if (created) return;
@@ -59,7 +61,10 @@ struct StageTimer {
             if (!(s.have[from[i]] && s.have[to[i]])) continue;
             if (hipEventSynchronize(s.ev[to[i]]) != hipSuccess) continue;
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, s.ev[from[i]], s.ev[to[i]]) == hipSuccess) { sum[i] += ms; cnt[i]++; hist[s.seq % HIST][i] = ms; }
+            if (hipEventElapsedTime(&ms, s.ev[from[i]], s.ev[to[i]]) == hipSuccess) {
+                sum[i] += ms; cnt[i]++; hist[s.seq % HIST][i] = ms;
+                hist_host[s.seq % HIST][i] = std::chrono::duration<float, std::milli>(s.host[to[i]] - s.host[from[i]]).count();
+            }
         }
         for (auto& h : s.have) h = false;
         s.used = false;
@@ -73,6 +78,7 @@ struct StageTimer {
         sets[cur].used = true;
         sets[cur].seq = calls++;
         for (auto& v : hist[sets[cur].seq % HIST]) v = -1.0f;
+        for (auto& v : hist_host[sets[cur].seq % HIST]) v = -1.0f;
     }
     void begin_backward()
     {
@@ -86,6 +92,7 @@ struct StageTimer {
         if (!g_timing) return;
         ensure();
         if (hipEventRecord(sets[cur].ev[i], st) != hipSuccess) { failures++; return; }
+        sets[cur].host[i] = std::chrono::steady_clock::now();
         sets[cur].have[i] = true;
     }
     void reset()
@@ -256,7 +263,7 @@ static void fill_frame(FrameParams& f, int P, int D, int M, const float* backgro
     f.scales = scales; f.rotations = rotations; f.cov3D_precomp = cov3D_precomp; f.viewmatrix = viewmatrix; f.projmatrix = projmatrix;
     f.inv_viewprojmatrix = inv_viewprojmatrix; f.cam_pos = cam_pos; f.prefiltered = prefiltered;
     f.wild_cov = 1; // (until the forward has read the status word: the kernels with the domain check)
-    f.log_depth = 0; f.log_need = nullptr;
+    f.log_depth = 0; f.log_need = nullptr; f.log_tag = 0;
 }
 
 } // namespace stp
@@ -613,7 +620,10 @@ int stp_timing_read(float* ms6) // the calling thread's current device
     return 0;
 }
 
-int stp_timing_history(float* ms6, int capacity) // the calling thread's current device
+static int timing_history(float* ms6, int capacity, bool host);
+int stp_timing_history(float* ms6, int capacity) { return timing_history(ms6, capacity, false); } // the calling thread's current device
+int stp_timing_history_host(float* ms6, int capacity) { return timing_history(ms6, capacity, true); }
+static int timing_history(float* ms6, int capacity, bool host)
 {
     if (!ms6 || capacity < 0) return fail(STP_ERR_INVALID_ARGUMENT, "null output");
     std::lock_guard<std::mutex> l(g_timer_mutex);
@@ -622,7 +632,7 @@ int stp_timing_history(float* ms6, int capacity) // the calling thread's current
     for (auto& s : t.sets) t.harvest(s);
     const long n = std::min<long>(std::min<long>(t.calls, StageTimer::HIST), capacity);
     for (long k = 0; k < n; k++) // chronological: the last n calls
-        std::memcpy(ms6 + 6 * k, t.hist[(t.calls - n + k) % StageTimer::HIST], 6 * sizeof(float));
+        std::memcpy(ms6 + 6 * k, (host ? t.hist_host : t.hist)[(t.calls - n + k) % StageTimer::HIST], 6 * sizeof(float));
     return (int)n;
 }
 
@@ -697,6 +707,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     const int log_depth = with_log ? log_depth_for(gslot, gkey) : 0;
     f.log_depth = log_depth;
     f.log_need = with_log ? log_need_word : nullptr;
+    const uint32_t log_tag = (uint32_t)((gkey >> 40) & 0xFFFFu) | 1u; // (never 0: an empty word carries no tag)
+    f.log_tag = log_tag;
     carve_image(nullptr, width, height, f.ty0, f.ty1, log_depth, &img_bytes); // (the tile-row window's share: see carve_image)
     char* img_ptr = (char*)image_alloc(image_user, img_bytes);
     if (!img_ptr) return fail(STP_ERR_ALLOC, "image allocator returned NULL");
@@ -857,7 +869,8 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     auto read_mailbox = [&](int* R_out, bool* wild_out) -> int {
         if (int rc = wait_mailbox()) return rc;
         const uint32_t host_status[2] = {mb.host[0], mb.host[1]};
-        if (const uint32_t reported = mb.host[3]) { // blends per pixel of the kind's last recording forward(s): never less than 31/32 of what was known
+        const uint32_t word = mb.host[3]; // (tag << 16 | blends per pixel): the report of the last recording forward(s) that used this slot's word
+        if (const uint32_t reported = (word >> 16) == log_tag ? (word & 0xFFFFu) : 0u) { // of THIS kind: never less than 31/32 of what was known
             const uint32_t known = gslot.key.load(std::memory_order_acquire) == gkey ? gslot.log_need.load(std::memory_order_relaxed) : 0u;
             const uint32_t keep = known - known / 32;
             gslot.log_need.store(reported > keep ? reported : keep, std::memory_order_relaxed);

@@ -45,6 +45,12 @@ size_t scan_temp_bytes(size_t P)
 // the side stream beside the sort, and without the fills in front of them the passes overlap more of it (clearing the states closer to a pass --
 // by the scan kernel, by the pass before -- or with a memset in front changed the passes' durations exactly as far as it delayed them).  What
 // counts is the stage: sort stage -10 .. -25 us on every workload (profiles/r04_tilesort_driver_ab.txt).
+// rocprim::detail is private, unversioned API: this driver is written against rocPRIM 4.2 (ROCm 7.2).  Another version must be looked at before it is
+// trusted -- the build stops here instead of mis-tuning or mis-launching silently; STP_TILE_SORT=rocprim (the library's own host function) is the
+// version-proof path and stays compiled in.
+#include <rocprim/rocprim_version.hpp>
+static_assert(ROCPRIM_VERSION_MAJOR == 4 && ROCPRIM_VERSION_MINOR == 2,
+              "stp_binning.hip drives rocprim::detail::onesweep_* of rocPRIM 4.2 directly: check the kernels' signatures and the gfx950 tuning against this rocPRIM version, then extend the assert");
 namespace {
 namespace rpd = rocprim::detail;
 using OsConfig = rpd::wrapped_radix_sort_onesweep_config<rocprim::default_config, uint64_t, uint32_t>;

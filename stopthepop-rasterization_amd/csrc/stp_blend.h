@@ -39,6 +39,7 @@ struct RenderArgs {
     uint32_t* blend_log;   // (storage; the records are log_t)
     int log_depth;         // records per pixel this frame's log holds (host: log_depth_for; the backward gets the forward's value)
     uint32_t* log_need;    // recording forwards: where the frame's largest blend count per pixel is reported (report_log_need), or nullptr
+    uint32_t log_tag;      // 16 bits that identify the frame's KIND in that word (the words are shared by the kinds that map to one guess slot)
     uint32_t* tile_flags;
     int flag_mode; // resorting backward: 0 = all tiles, 1 = only tiles with tile_flags != 0
     // debug depth visualisation (StpSettings::debug_visualization == STP_DEBUG_DEPTH): the forward kernels write
@@ -76,12 +77,18 @@ __device__ __forceinline__ char* log_wave_slice(uint32_t* blend_log, int tile, i
 }
 // what a recording forward reports back: the largest number of blends of any of its pixels (one compare per wave, an atomic only while
 // the maximum still rises), collected per device and kind and handed to the host with the next forward's num_rendered
-__device__ __forceinline__ void report_log_need(uint32_t* word, int nrec)
+// (the word carries the reporting kind's tag in its upper half: a forward of another kind that shares the slot does not take the report for its own)
+__device__ __forceinline__ void report_log_need(uint32_t* word, int nrec, uint32_t tag)
 {
     int m = nrec;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
-    if (word != nullptr && (threadIdx.x & 63) == 0 && (uint32_t)m > *reinterpret_cast<volatile uint32_t*>(word)) atomicMax(word, (uint32_t)m);
+    if (word != nullptr && (threadIdx.x & 63) == 0) {
+        const uint32_t v = (tag << 16) | (uint32_t)min(m, 0xFFFF);
+        const uint32_t old = *reinterpret_cast<volatile uint32_t*>(word);
+        if ((old >> 16) != tag) atomicExch(word, v);   // another kind's (or no) report: ours replaces it
+        else if (v > old) atomicMax(word, v);
+    }
 }
 
 struct FwdPixel {

@@ -149,6 +149,7 @@ struct FrameParams {
     int prefiltered;
     int log_depth;       // depth of this frame's blend log (forward: chosen by log_depth_for; backward: the forward's)
     uint32_t* log_need;  // forward: device word the recording kernels report their largest blend count per pixel to (or nullptr)
+    uint32_t log_tag;    // ... tagged with 16 bits of the frame's kind
     int wild_cov; // forward, after the status read-back: some visible Gaussian has a Sigma^-1 entry >= 1e36 or not finite (depth keys then take the reciprocal with its domain check)
 };
 

@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     }
     if constexpr (RECORD) {
         if (log_records() > a.log_depth || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u; // log overflow: this tile's backward re-sorts
-        report_log_need(a.log_need, log_records());
+        report_log_need(a.log_need, log_records(), a.log_tag);
     }
 }
 
@@ -671,7 +671,7 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     }
     if constexpr (RECORD) {
         if (log_records() > a.log_depth || total > LOG_MAX_LIST) a.tile_flags[tile] = 1u;
-        report_log_need(a.log_need, log_records());
+        report_log_need(a.log_need, log_records(), a.log_tag);
     }
 }
 

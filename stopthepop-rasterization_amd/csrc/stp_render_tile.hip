@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
         }
         if constexpr (RECORD) {
             if (nrec > a.log_depth || total > LOG_MAX_LIST) a.tile_flags[c.tile] = 1u; // log overflow: this tile's backward re-sorts
-            report_log_need(a.log_need, nrec);
+            report_log_need(a.log_need, nrec, a.log_tag);
         }
     }
 }
@@ -413,7 +413,7 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     a.final_T = img.final_T; a.n_contrib = img.n_contrib;
     a.blend_log = img.blend_log; a.tile_flags = img.tile_flags; a.flag_mode = 0;
-    a.log_depth = img.log_depth; a.log_need = f.log_need;
+    a.log_depth = img.log_depth; a.log_need = f.log_need; a.log_tag = f.log_tag;
     a.debug_depth = f.s.debug_visualization == STP_DEBUG_DEPTH ? 1 : 0; a.means3D = f.means3D;
     return a;
 }

@@ -88,6 +88,8 @@ def _load():
     L.stp_hbm_probe.restype = ci
     L.stp_timing_history.argtypes = [ctypes.POINTER(ctypes.c_float), ci]
     L.stp_timing_history.restype = ci
+    L.stp_timing_history_host.argtypes = [ctypes.POINTER(ctypes.c_float), ci]
+    L.stp_timing_history_host.restype = ci
     L.stp_timing_text.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
     L.stp_timing_text.restype = ctypes.c_size_t
     L.stp_binning_layout_count.argtypes = [vp, ci]
@@ -442,12 +444,13 @@ def hbm_probe(kind: str, dst, src, blocks: int = 4096, nontemporal: bool = False
         raise RuntimeError(f"stp_hbm_probe failed ({rc})")
 
 
-def timing_history(device=None, capacity=1024):
+def timing_history(device=None, capacity=1024, host=False):
     """Stage times of the last (up to `capacity`) timed calls on `device`, one dict per forward(+backward) in chronological order;
-    a stage that was not measured in a call is missing from its dict."""
+    a stage that was not measured in a call is missing from its dict.  host=True: the launching thread's own time between the stage's two
+    event records instead of the GPU interval (a long GPU interval with an equally long host one = the launches came late)."""
     arr = (ctypes.c_float * (6 * capacity))()
     with _on_device(device):
-        n = _load().stp_timing_history(arr, capacity)
+        n = (_load().stp_timing_history_host if host else _load().stp_timing_history)(arr, capacity)
     if n < 0:
         _raise_last(n)
     names = ("Preprocess", "Duplicate", "Sort", "Render", "BwdRender", "BwdPreprocess")
