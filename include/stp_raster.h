@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define STP_ABI_VERSION 6
+#define STP_ABI_VERSION 7
 #define STP_GRAD_RECORD_FLOATS 16 /* floats per Gaussian in grad_records (see stp_backward) */
 #define STP_GRAD_RECORD_USED 9    /* of which these carry data; the record stride of stp_backward_phases' compact form (phases bit 2) */
 

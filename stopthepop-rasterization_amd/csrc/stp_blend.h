@@ -53,7 +53,7 @@ struct RenderArgs {
 typedef uint16_t log_t;
 constexpr int LOG_MAX_LIST = 65535;
 #ifndef STP_LOG_PACK
-#define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured)
+#define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured, see profiles/EXPERIMENTS.md)
 #endif
 // Depth of the log = records per pixel it can hold (2 B each; + one spare row, STP_LOG_UNCOND): a RUN-TIME value since round 4
 // (RenderArgs::log_depth), chosen per frame by the host from the blends per pixel the previous recording forwards of the same kind

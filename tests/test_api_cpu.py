@@ -113,16 +113,16 @@ def test_native_host_binding_loads_and_binds_the_c_abi():
     for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "mark_visible", "scratch_generation", "check_scratch", "release_scratch",
                  "clear_scratch_pool", "set_scratch_pool_limit", "pooled_sizes", "load_library"):
         assert callable(getattr(h, name)), name
-    assert h.load_library(_C.library_path()) == 6
+    assert h.load_library(_C.library_path()) == 7
     assert _C.clear_scratch_pool() == 0 and list(h.pooled_sizes(0)) == []
     with pytest.raises(RuntimeError, match="cannot load"):
         h.load_library("/nonexistent/libstp_raster.so")
-    assert h.load_library(_C.library_path()) == 6   # (a failed load leaves the bound library in place)
+    assert h.load_library(_C.library_path()) == 7   # (a failed load leaves the bound library in place)
 
 
 def test_c_abi_size_and_layout_queries_without_gpu():
     L = _C._load()
-    assert L.stp_abi_version() == 6
+    assert L.stp_abi_version() == 7
     s = _C.settings_from_dict(dgr.ExtendedSettings().to_dict())
     small, big = L.stp_geometry_buffer_size(1000, ctypes.byref(s)), L.stp_geometry_buffer_size(2000, ctypes.byref(s))
     assert 0 < small < big
