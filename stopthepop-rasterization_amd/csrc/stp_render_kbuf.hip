@@ -84,6 +84,16 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     const int px = cx + 2 * (m & 1) + (q & 1), py = cy + 2 * (m >> 1) + (q >> 1);
     const bool inside = px < a.W && py < a.H;
     bool active = inside;
+    if (total <= 0) { // an empty tile is background (and its "entry 0" -- what pads and stand-ins read -- may not exist: stp_render_hier.inc)
+        if (inside) {
+            const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
+            a.final_T[pid] = 1.0f;
+            a.n_contrib[pid] = 0u;
+            if constexpr (DEPTHVIZ) { a.out_color[pid] = 0.0f; a.out_color[N + pid] = 1.0f; }
+            else { a.out_color[pid] = a.bg[0]; a.out_color[N + pid] = a.bg[1]; a.out_color[2 * N + pid] = a.bg[2]; }
+        }
+        return;
+    }
 
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
     const float3 pix_dir = view_ray(a.inv_vp, cam, (float)px, (float)py, a.W, a.H);
@@ -380,6 +390,16 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     const int px = cx + 2 * (m & 1) + (q & 1), py = cy + 2 * (m >> 1) + (q >> 1);
     const bool inside = px < a.W && py < a.H;
     bool active = inside;
+    if (total <= 0) { // an empty tile is background (and its "entry 0" -- what pads and stand-ins read -- may not exist: stp_render_hier.inc)
+        if (inside) {
+            const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
+            a.final_T[pid] = 1.0f;
+            a.n_contrib[pid] = 0u;
+            if constexpr (DEPTHVIZ) { a.out_color[pid] = 0.0f; a.out_color[N + pid] = 1.0f; }
+            else { a.out_color[pid] = a.bg[0]; a.out_color[N + pid] = a.bg[1]; a.out_color[2 * N + pid] = a.bg[2]; }
+        }
+        return;
+    }
 
     const float3 cam = make_float3(a.cam[0], a.cam[1], a.cam[2]);
     const float3 pix_dir = view_ray(a.inv_vp, cam, (float)px, (float)py, a.W, a.H);

@@ -105,7 +105,11 @@ class GpuRun:
         self.color = color.detach().cpu().numpy()
         self.radii = radii.cpu().numpy()
         if self.exact_pass is not None:   # exact path == run-ahead path, bit for bit (NaN == NaN: render_depth of an empty frame)
-            assert torch.equal(torch.nan_to_num(self.exact_pass[1], nan=-1.0), torch.nan_to_num(color.detach(), nan=-1.0)), "run-ahead forward differs from the exact one"
+            if not torch.equal(torch.nan_to_num(self.exact_pass[1], nan=-1.0), torch.nan_to_num(color.detach(), nan=-1.0)):
+                a_, b_ = self.exact_pass[1].cpu().numpy(), color.detach().cpu().numpy()
+                bad = np.argwhere((a_ != b_) & ~(np.isnan(a_) & np.isnan(b_)))
+                raise AssertionError(f"run-ahead forward differs from the exact one: {len(bad)} values, rows {bad[:, 1].min()}..{bad[:, 1].max()}, cols {bad[:, 2].min()}..{bad[:, 2].max()}, "
+                                     f"exact {a_[tuple(bad[0])]} run-ahead {b_[tuple(bad[0])]}, counts {self.exact_pass[0]} / {getattr(color.grad_fn, 'num_rendered', None)}")
             assert torch.equal(self.exact_pass[2], radii)
         fn = color.grad_fn
         if fn is not None:

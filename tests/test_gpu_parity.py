@@ -57,13 +57,19 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-
     assert diff.max() <= 1.0 / 255.0 + 1e-6
     moved = diff > img_tol
     flipped = int(moved.sum())
-    if flipped:
+    if flipped or diff.max() > 2e-6:
         from oracle import explain
-        ex = explain.explain_moved_pixels(moved.any(axis=0), W=scene.W, H=scene.H, ranges=f.array("ranges").reshape(-1), point_list=f.array("point_list"),
-                                          conic_opacity=f.array("conic_opacity").reshape(-1), means2D=f.array("means2D").reshape(-1),
-                                          final_T_a=g.image_array("final_T").reshape(-1), final_T_b=f.array("final_T").reshape(-1),
-                                          cull_4x4=bool(sd["culling_settings"]["hierarchical_4x4_culling"]) and sd["sort_settings"]["sort_mode"] == 3)
-        assert not ex["unexplained"], (flipped, ex["by"], ex["unexplained"][:5])
+        probe = lambda mask: explain.explain_moved_pixels(mask, W=scene.W, H=scene.H, ranges=f.array("ranges").reshape(-1), point_list=f.array("point_list"),
+                                                          conic_opacity=f.array("conic_opacity").reshape(-1), means2D=f.array("means2D").reshape(-1),
+                                                          final_T_a=g.image_array("final_T").reshape(-1), final_T_b=f.array("final_T").reshape(-1),
+                                                          cull_4x4=bool(sd["culling_settings"]["hierarchical_4x4_culling"]) and sd["sort_settings"]["sort_mode"] == 3)
+        if flipped:
+            ex = probe(moved.any(axis=0))
+            assert not ex["unexplained"], (flipped, ex["by"], ex["unexplained"][:5])
+        elif probe((diff > 2e-6).any(axis=0))["explained"]:
+            # a decision on its threshold that moved its pixel by less than img_tol (a faint Gaussian deep in a dense scene): the pixel passes as it is,
+            # but that Gaussian's gradient still carries the whole blend -- the gradient tolerance of a flipped frame applies
+            flipped = 1
     assert psnr(g.color, f.color) >= (100.0 if flipped == 0 else 75.0)  # (one flipped pixel of a 1600-pixel image: 80 dB)
     # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
     # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise
@@ -899,3 +905,23 @@ def test_per_gaussian_half_by_id_range():
             assert torch.equal(a, w)
     with pytest.raises(RuntimeError):
         _C.rasterize_gaussians_backward(*args, phases=2 | 4 | (2 << 8) | (5 << 16), partial=records)   # chunk 5 of 2
+
+
+@pytest.mark.parametrize("sd", [settings_dict(**FULL_STP), settings_dict(3), settings_dict(2, per_pixel=2), settings_dict(2, per_pixel=16)],
+                         ids=["full_stp", "hier", "kbuffer2", "kbuffer16"])
+def test_frame_without_any_entry_is_background_whatever_the_memory_holds(sd):
+    """The per-pixel-sort forwards let pads and stand-ins read "entry 0 of the tile's list" and weigh it with zero.  In a frame without ANY
+    tile-list entry behind a run-ahead launch (num_rendered == 0, capacity > 0) the entry records are never written: with NaN in that memory
+    0 x NaN reached the image (found by tools/fuzz_parity.py in round 5: tile-row windows over empty rows).  Empty tiles are background by an
+    early exit now; here the allocator's free memory is poisoned with NaN first."""
+    sc = scenes.make_scene(P=300, W=100, H=70, sigma_min=2.0, sigma_max=6.0, seed=3)
+    sc.means3D[:, 2] = -5.0                  # every Gaussian behind the camera: no tile-list entry in the whole frame
+    for rows in (None, (1, 3)):
+        for _ in range(2):
+            poison = torch.full((48 << 20,), float("nan"), device="cuda:0")
+            del poison                       # (back to the caching allocator: the next buffers are cut from it)
+            g = GpuRun(sc, sd, backward=False, tile_rows=rows)   # exact pass, then the run-ahead pass (helpers.py)
+            assert g.num_rendered == 0
+            win = g.color if rows is None else g.color[:, 16 * rows[0]:min(16 * rows[1], sc.H)]
+            assert not np.isnan(g.color).any()
+            assert np.array_equal(win, np.broadcast_to(np.asarray(sc.bg, np.float32)[:, None, None], win.shape))

@@ -96,7 +96,7 @@ def main():
                 f, _ = oracle_run(scene, settings_dict(**sd), backward=False, tile_rows=(y0, y1))
                 rows = slice(16 * y0, min(16 * y1, scene.H))
                 dd = np.abs(g.color[:, rows].astype(np.float64) - f.color[:, rows])
-                assert g.num_rendered == f.num_rendered and dd.max() <= 1.0 / 255.0 + 1e-6 and int((dd > 2e-6).sum()) <= 6, ("tile rows", y0, y1, float(dd.max()))
+                assert g.num_rendered == f.num_rendered and dd.max() <= 1.0 / 255.0 + 1e-6 and int((dd > 2e-6).sum()) <= 6, ("tile rows", y0, y1, float(dd.max()), int(np.isnan(g.color[:, rows]).sum()), int(np.isnan(f.color[:, rows]).sum()), g.num_rendered)
             elif args.heavy:  # ~500-1000 blends per pixel: rounding of the transmittance product accumulates (seen: 2e-5), faint
                 # Gaussians (opacity at the 1/255 threshold) have gradients that hang on single threshold decisions
                 # and the 4x4 culling test is such a decision for a whole sub-tile (16 pixels x 3 channels at once)
@@ -112,6 +112,9 @@ def main():
             bad += 1
             tb = traceback.extract_tb(e.__traceback__)[-1]
             print(f"FAIL case {i}: scene={sc} settings={sd}: {type(e).__name__}: {str(e)[:200]} @ {tb.filename.split('/')[-1]}:{tb.lineno}", flush=True)
+            if os.environ.get("FUZZ_TRACE"):
+                print(f"   sh_degree={scene.sh_degree} scale_modifier={scene.scale_modifier}")
+                print("   " + "\n   ".join(traceback.format_exc().splitlines()[-14:]), flush=True)
         done += 1
     print(f"fuzz: {done} cases, {bad} failures, {time.time() - t0:.0f} s")
     sys.exit(1 if bad else 0)
