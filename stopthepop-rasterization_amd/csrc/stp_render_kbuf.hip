@@ -60,6 +60,23 @@ __device__ __forceinline__ int kb_remap_tile(int wg, int n_wg)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
+// can the entry with record rows C (mean in .yz) and D (conic, opacity) reach 1/255 at any of the four pixels of the 2x2 quad whose CENTRE is (qxc, qyc)?
+// (stp_render_hier.inc quad_can_blend: an upper bound of opacity * exp(power) over the four pixels that covers every rounding of the per-pixel
+// evaluation; NaN is kept, the exact test decides)
+__device__ __forceinline__ bool kb_quad_can_blend(const float4 C, const float4 D, const float qxc, const float qyc)
+{
+    const float dx = C.y - qxc, dy = C.z - qyc;
+    const float gx = fmaf(D.y, dy, D.x * dx), gy = fmaf(D.z, dy, D.y * dx);
+    const float q2 = fmaf(gy, dy, gx * dx);
+    const float m2 = fminf(fmaf(D.y, 0.5f, -fabsf(gx + gy)), fmaf(D.y, -0.5f, -fabsf(gx - gy)));
+    const float qmin2 = fmaf(D.x + D.z, 0.25f, q2) + m2; // 2 x the smallest negated exponent among the four pixels
+    const float far = fmaxf(fabsf(dx), fabsf(dy)) + 0.5f;
+    const float S = (fabsf(D.x) + fabsf(D.z) + fabsf(D.y)) * far * far;
+    const float pup = fmaf(qmin2, -0.5f, S * 2.0e-6f);
+    const float v = D.w * __builtin_amdgcn_exp2f(pup * 1.44269502162933349609375f);
+    return !(v < ALPHA_THRESHOLD * 0.9999f);
+}
+
 constexpr int KBW_FWD = 0, KBW_RECORD = 2, KBW_DEPTH = 3; // (the values of the hierarchical kernel's modes)
 
 template <int WIN> constexpr int kb_waves() { return WIN <= 4 ? 4 : WIN <= 16 ? 3 : 2; } // waves per SIMD the kernel is compiled for
@@ -211,21 +228,6 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
 #undef STP_KB_FEED
     };
 
-    // can the entry reach 1/255 at any of the quad's four pixels?  (stp_render_hier.inc quad_can_blend: an upper bound of
-    // opacity * exp(power) over the four pixels that covers every rounding of the per-pixel evaluation)
-    auto quad_can_blend = [&](const float4 C, const float4 D, const float qxc, const float qyc) __attribute__((always_inline)) -> bool { // (qxc, qyc): the quad's centre
-        const float dx = C.y - qxc, dy = C.z - qyc;
-        const float gx = fmaf(D.y, dy, D.x * dx), gy = fmaf(D.z, dy, D.y * dx);
-        const float q2 = fmaf(gy, dy, gx * dx);
-        const float m2 = fminf(fmaf(D.y, 0.5f, -fabsf(gx + gy)), fmaf(D.y, -0.5f, -fabsf(gx - gy)));
-        const float qmin2 = fmaf(D.x + D.z, 0.25f, q2) + m2; // 2 x the smallest negated exponent among the four pixels
-        const float far = fmaxf(fabsf(dx), fabsf(dy)) + 0.5f;
-        const float S = (fabsf(D.x) + fabsf(D.z) + fabsf(D.y)) * far * far;
-        const float pup = fmaf(qmin2, -0.5f, S * 2.0e-6f);
-        const float v = D.w * __builtin_amdgcn_exp2f(pup * 1.44269502162933349609375f);
-        return !(v < ALPHA_THRESHOLD * 0.9999f); // NaN: kept, the exact test decides
-    };
-
     int* const hfifo = s_fifo + ((w * 4 + s) * 4 + m) * KB_CAP;
     int hf_head = 0, hf_cnt = 0; // (quad-uniform)
     auto head_round = [&](const bool force) __attribute__((always_inline)) -> bool { // false: nothing (more) to do now
@@ -306,7 +308,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
                 bool keep = false;
                 const unsigned long long act = __ballot(active);
                 const bool qlive = ((act >> (lane & ~3)) & 0xFull) != 0ull;
-                if (fid >= 0 && qlive) keep = quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qxc, qyc);
+                if (fid >= 0 && qlive) keep = kb_quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qxc, qyc);
                 int bits = keep ? (1 << q) : 0;
                 bits += __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xF, 0xF, true); // quad_perm [1,0,3,2]
                 bits += __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xF, 0xF, true); // quad_perm [2,3,0,1]
@@ -575,19 +577,6 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
 #undef STP_KB_FEED
     };
 
-    auto quad_can_blend = [&](const float4 C, const float4 D, const float qxc, const float qyc) __attribute__((always_inline)) -> bool { // (see the kernel above)
-        const float dx = C.y - qxc, dy = C.z - qyc;
-        const float gx = fmaf(D.y, dy, D.x * dx), gy = fmaf(D.z, dy, D.y * dx);
-        const float q2 = fmaf(gy, dy, gx * dx);
-        const float m2 = fminf(fmaf(D.y, 0.5f, -fabsf(gx + gy)), fmaf(D.y, -0.5f, -fabsf(gx - gy)));
-        const float qmin2 = fmaf(D.x + D.z, 0.25f, q2) + m2;
-        const float far = fmaxf(fabsf(dx), fabsf(dy)) + 0.5f;
-        const float S = (fabsf(D.x) + fabsf(D.z) + fabsf(D.y)) * far * far;
-        const float pup = fmaf(qmin2, -0.5f, S * 2.0e-6f);
-        const float v = D.w * __builtin_amdgcn_exp2f(pup * 1.44269502162933349609375f);
-        return !(v < ALPHA_THRESHOLD * 0.9999f);
-    };
-
     int* const hfifo = s_fifo + ((w * 4 + s) * 4 + m) * KBR_CAP;
     int hf_head = 0, hf_cnt = 0; // (quad-uniform)
     auto fwrap = [&](int v) __attribute__((always_inline)) -> int { // v in [0, 3 KBR_CAP) -> [0, KBR_CAP)
@@ -654,7 +643,7 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
                 bool keep = false;
                 const unsigned long long act = __ballot(active);
                 const bool qlive = ((act >> (lane & ~3)) & 0xFull) != 0ull;
-                if (fid >= 0 && qlive) keep = quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qxc, qyc);
+                if (fid >= 0 && qlive) keep = kb_quad_can_blend(ent_row(eC, fid), ent_row(eD, fid), qxc, qyc);
                 int bits = keep ? (1 << q) : 0;
                 bits += __builtin_amdgcn_mov_dpp(bits, 0xB1, 0xF, 0xF, true);
                 bits += __builtin_amdgcn_mov_dpp(bits, 0x4E, 0xF, 0xF, true);
@@ -722,7 +711,7 @@ hipError_t launch_kbuffer_wave(int mode, const FrameParams& f, const RenderArgs&
     *handled = true;
     // windows of 8 .. 16 entries: the ring-in-LDS kernel (STP_KBUFFER=wave keeps the register window for them too)
     static const char* const kb_env = std::getenv("STP_KBUFFER");
-    static const bool ring = !(kb_env && std::strcmp(kb_env, "wave") == 0);
+    static const bool ring = !STP_LOG_PACK && !(kb_env && std::strcmp(kb_env, "wave") == 0); // (the ring kernel writes the plain log layout only)
 #define STP_KBW(WIN) return mode == KBW_RECORD ? launch_kb_win<WIN, KBW_RECORD>(f, a, st) : mode == KBW_DEPTH ? launch_kb_win<WIN, KBW_DEPTH>(f, a, st) : launch_kb_win<WIN, KBW_FWD>(f, a, st)
 #define STP_KBR(WIN) return mode == KBW_RECORD ? launch_kb_ring<WIN, KBW_RECORD>(f, a, st) : mode == KBW_DEPTH ? launch_kb_ring<WIN, KBW_DEPTH>(f, a, st) : launch_kb_ring<WIN, KBW_FWD>(f, a, st)
     if (w <= 1) STP_KBW(1);

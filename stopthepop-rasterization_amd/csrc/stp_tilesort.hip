@@ -23,6 +23,10 @@ namespace {
 // gather wants many workgroups per CU) takes the tiles with up to TS_SMALL entries and leaves at once on the others,
 // LARGE (32 KB) takes the rest, up to TS_CAP in LDS and beyond that through the counting passes.
 constexpr int TS_SMALL = 1024, TS_CAP = 4096;
+#ifndef STP_GATHER_WAVES
+#define STP_GATHER_WAVES 6 // waves per SIMD the small instantiation is compiled for: 80 VGPRs as the compiler likes it = 6.  MEASURED (round 5, after the
+                           // hierarchical forward gained 7 % from a fifth wave): 8 waves = 64 VGPRs + 32 B of scratch: sort stage 0.3157 / 0.3151 / 0.3161 -> 0.3180 / 0.3201 / 0.3204 ms
+#endif
 
 struct TileSortArgs {
     const uint2* ranges;
@@ -104,7 +108,7 @@ template <int IPT> struct TileRadix {
 };
 
 template <int CAP, int MIN_N>
-__global__ void __launch_bounds__(256) tile_sort_gather_kernel(const TileSortArgs a)
+__global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4)) tile_sort_gather_kernel(const TileSortArgs a)
 {
     using Radix8 = TileRadix<8>;
     using Radix16 = TileRadix<16>;
