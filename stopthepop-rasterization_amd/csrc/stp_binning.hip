@@ -54,7 +54,30 @@ static_assert(ROCPRIM_VERSION_MAJOR == 4 && ROCPRIM_VERSION_MINOR == 2,
 namespace {
 namespace rpd = rocprim::detail;
 using OsConfig = rpd::wrapped_radix_sort_onesweep_config<rocprim::default_config, uint64_t, uint32_t>;
-constexpr rpd::radix_sort_onesweep_config_params OS = OsConfig::architecture_config<rpd::target_arch::gfx950>::params;
+constexpr rpd::radix_sort_onesweep_config_params os_params()
+{
+    rpd::radix_sort_onesweep_config_params p = OsConfig::architecture_config<rpd::target_arch::gfx950>::params; // 512 threads x 16 keys, 8 bits per place
+    // The library's 8192 keys per workgroup leave a C2 frame (2.6 M entries) with 320 workgroups = 2.5 waves per SIMD for a scatter that lives on
+    // memory parallelism.  MEASURED in the frame (round 5, two boxes, three alternating rounds each, profiles/r05_experiments/onesweep_tuning.txt):
+    // 512 x 8 sort stage 0.318 -> 0.300 and 0.330 -> 0.314 ms at C2-full, C3 0.987 -> 0.971, C5 1.211 -> 1.197, C2-min / C4 unchanged; 512 x 12 -16 / -7 us,
+    // 512 x 10 -7, 512 x 6 -5, 256 x 16 -10, 256 x 12 -8, 256 x 8 +4, 1024 x 4 -6, 1024 x 6 -2.  (Round 4 had tried 512 x 12 under the library's own
+    // driver, whose fills in front of every pass hid the difference.)
+    p.sort.items_per_thread = 8;
+#ifdef STP_OS_SORT_BLOCK
+    p.sort.block_size = STP_OS_SORT_BLOCK;
+#endif
+#ifdef STP_OS_SORT_IPT
+    p.sort.items_per_thread = STP_OS_SORT_IPT;
+#endif
+#ifdef STP_OS_HIST_BLOCK
+    p.histogram.block_size = STP_OS_HIST_BLOCK;
+#endif
+#ifdef STP_OS_HIST_IPT
+    p.histogram.items_per_thread = STP_OS_HIST_IPT;
+#endif
+    return p;
+}
+constexpr rpd::radix_sort_onesweep_config_params OS = os_params();
 constexpr unsigned OS_RADIX = 1u << OS.radix_bits_per_place;
 constexpr unsigned OS_HIST_ITEMS = OS.histogram.block_size * OS.histogram.items_per_thread;
 constexpr unsigned OS_SORT_ITEMS = OS.sort.block_size * OS.sort.items_per_thread;
@@ -105,6 +128,9 @@ __global__ void __launch_bounds__(OS.sort.block_size) os_iteration_kernel(const 
         keys_in, keys_out, values_in, values_out, size, offsets_in, offsets_out, lookback, rocprim::identity_decomposer{}, bit, radix_bits, full_blocks, ordered_bid);
 }
 
+// (One kernel for the histograms AND their scans -- workgroup histograms in LDS, the last workgroup by ticket scans in place -- was built and
+// measured in round 5: sort stage equal to these two library kernels within 3 us in four A/B runs; removed.  What it taught: a device-scope
+// __threadfence() behind duplicate_kernel's 31 MB of keys writes the XCD's L2 back and cost 200 us; profiles/EXPERIMENTS.md, round 5.)
 // (below OWN_MIN entries the library sorts with ONE workgroup-sort kernel: nothing to gain from four launches of our own)
 constexpr uint32_t OWN_MIN = 1u << 16, OWN_MAX = 1u << 30;
 bool own_onesweep_driver(size_t R)

@@ -43,6 +43,9 @@ struct TileSortArgs {
     float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
 };
 
+#ifndef STP_BITONIC_WAVE
+#define STP_BITONIC_WAVE 1 // 0: a workgroup barrier behind every stage of the bitonic network
+#endif
 #ifndef STP_GATHER_ABLATE
 #define STP_GATHER_ABLATE 0 // timing experiments (results WRONG): 1 = no sub-tile masks, 2 = no colour read, 3 = no gpack read (constants), 4 = no entry stores, 5 = no sort network.
                            // MEASURED (round 4, C2-full, sort stage 0.330 ms, two alternating rounds): without the masks -15 us, without the colour read -22,
@@ -145,6 +148,9 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
             s_key[i] = i < n ? ((keys[i] << 32) | list[i]) : ~0ull;
         }
         __syncthreads();
+        // A stage with partner distance j <= 64 keeps every wave inside its own 128 keys (the 64 consecutive comparators c of a wave cover keys
+        // [128 (c / 64), 128 (c / 64) + 128)): between two such stages the wave's own LDS order is all the synchronisation there is to need --
+        // a workgroup barrier only around the stages that cross waves (3 of the 45 stages of a 512-key network, 6 of 55 at 1024 keys).
         for (int k = 2; k <= (STP_GATHER_ABLATE == 5 ? 0 : m); k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int c = tid; c < (m >> 1); c += 256) {
@@ -154,7 +160,10 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
                     const uint64_t x = s_key[lo], y = s_key[hi];
                     if ((x > y) == up) { s_key[lo] = y; s_key[hi] = x; }
                 }
-                __syncthreads();
+                const int j_next = j > 1 ? (j >> 1) : k; // (the first distance of the next merge; behind the last stage: the read-out, which crosses waves)
+                const bool last = j == 1 && k == m;
+                if (!STP_BITONIC_WAVE || j > 64 || j_next > 64 || last) __syncthreads();
+                else wave_sync();
             }
         for (int i = tid; i < n; i += 256) {
             const uint64_t k = s_key[i];
