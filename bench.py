@@ -297,38 +297,54 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
     M = 16
     alg = survey_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, ewa)
     des = design_bytes(P, P_v, R, N, T, M, S, mode, Kf, E, 1, B if recording else 0)
-    dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
-    dom_key = "render_bwd" if dom == "BwdRender" else "render_fwd"
-    dom_ms = stage_ms.get(dom, float("nan"))
-    achieved = alg[dom_key] / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
-    if mode == 3:
-        # (last template argument: the depth keys' reciprocal without its domain check -- the default queue sizes'
-        # forward passes on a frame whose Sigma^-1 is tame, which every synthetic workload is)
-        frcp = "true" if (head == 4 and mid == 8) else "false"
-        kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
-            else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
-    elif mode == 2:
-        win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
-        kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
-            (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
-             f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>")
-    else:
-        kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
-    prof, prof_note = profile_entry(kname, f"{wl.name}-{wl.variant}")
     fwd_keys, bwd_keys = ("preprocess", "scan", "duplicate", "sort", "ranges", "render_fwd"), ("zero_fill", "render_bwd", "bwd_cov2D", "bwd_preprocess")
     fwd_bytes = sum(alg[k] for k in fwd_keys)
     bwd_bytes = sum(alg[k] for k in bwd_keys)
     step_bytes = fwd_bytes + (0 if fwd_only else bwd_bytes)
-    valu_bound = mode in (2, 3)   # the re-sorting render kernels and the replay are VALU-issue / latency bound (PMC: profiles/), not HBM bound
-    roofline = {"bound": "valu" if valu_bound else "hbm", "priced_on": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(prof["hbm_bytes_per_launch"]) if prof else None,
-                "traffic_source": prof_note,
-                "algorithmic_bytes_per_launch": int(alg[dom_key]), "bytes_model": "SURVEY.md section 8(d), verbatim",
-                "design_bytes_per_launch": int(des[dom_key]), "avg_launch_ms": round(dom_ms, 4),
-                "whole_step_frac": round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5),
-                "note": ("what bounds this kernel is VALU issue (see \"roofline_valu\" / \"valu\"): achieved / peak / frac here are its HBM figures -- SURVEY 8(d) "
-                         "bytes per launch over the launch duration against 8 TB/s -- which the contract asks for") if valu_bound else
-                        "streaming kernel: achieved / peak / frac are SURVEY 8(d) bytes per launch over the launch duration against 8 TB/s"}
+
+    def roof_for(dom):
+        """The roofline object of one of the two render kernels ("Render" / "BwdRender")."""
+        dom_key = "render_bwd" if dom == "BwdRender" else "render_fwd"
+        dom_ms = stage_ms.get(dom, float("nan"))
+        achieved = alg[dom_key] / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else float("nan")
+        if mode == 3:
+            # (last template argument: the depth keys' reciprocal without its domain check -- the default queue sizes'
+            # forward passes on a frame whose Sigma^-1 is tame, which every synthetic workload is)
+            frcp = "true" if (head == 4 and mid == 8) else "false"
+            kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
+                else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
+        elif mode == 2:
+            win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
+            kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
+                (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
+                 f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>")
+        else:
+            kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
+        prof, prof_note = profile_entry(kname, f"{wl.name}-{wl.variant}")
+        # What bounds the kernel (PMC passes under profiles/): the re-sorting forwards issue VALU instructions 93-96 % of the time; the replay waits for the LDS atomic unit
+        # (sums on shared addresses: VALU 68 %, LDS 51 % busy, and neither more waves nor spreading the adds out helps -- profiles/EXPERIMENTS.md, round 5)
+        bound = "hbm" if mode not in (2, 3) else ("lds" if kname == "render_replay_kernel" else "valu")
+        note = {"hbm": "streaming kernel: achieved / peak / frac are SURVEY 8(d) bytes per launch over the launch duration against 8 TB/s",
+                "valu": "what bounds this kernel is VALU issue (see \"roofline_valu\" / \"valu\"): achieved / peak / frac here are its HBM figures -- SURVEY 8(d) "
+                        "bytes per launch over the launch duration against 8 TB/s -- which the contract asks for",
+                "lds": "what bounds this kernel is the LDS atomic unit (64-bit fixed-point sums of lanes that share list positions; see \"valu\" for its VALU side): achieved / peak / "
+                       "frac here are its HBM figures -- SURVEY 8(d) bytes per launch over the launch duration against 8 TB/s -- which the contract asks for"}[bound]
+        roofline = {"bound": bound, "priced_on": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": int(prof["hbm_bytes_per_launch"]) if prof else None,
+                    "traffic_source": prof_note,
+                    "algorithmic_bytes_per_launch": int(alg[dom_key]), "bytes_model": "SURVEY.md section 8(d), verbatim",
+                    "design_bytes_per_launch": int(des[dom_key]), "avg_launch_ms": round(dom_ms, 4),
+                    "whole_step_frac": round((step_bytes / (ms_per_step * 1e-3) / 1e9) / HBM_PEAK_GBS, 5),
+                    "note": note}
+        return roofline, kname, dom_ms, prof, prof_note
+
+    # the dominant kernel is the longer of the two render kernels; at C2-full they are within 1 % of each other and which one leads changes from box to box: the other one's
+    # object rides along as "second" so that both are on every line
+    dom = "BwdRender" if (not fwd_only and stage_ms.get("BwdRender", 0) >= stage_ms.get("Render", 0)) else "Render"
+    roofline, kname, dom_ms, prof, prof_note = roof_for(dom)
+    if not fwd_only and "BwdRender" in stage_ms:
+        second = roof_for("Render" if dom == "BwdRender" else "BwdRender")[0]
+        roofline["second"] = {k: second[k] for k in ("bound", "kernel", "achieved", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms")}
     info = {"P": P, "P_visible": P_v, "num_rendered": R, "tiles": T, "blended_pairs": B, "mode": mode, "order": order,
             "alg": alg, "des": des, "fwd_bytes": fwd_bytes, "bwd_bytes": bwd_bytes, "kname": kname, "dom_ms": dom_ms,
             "prof": prof, "prof_note": prof_note}
@@ -712,7 +728,8 @@ def main():
             peak = 1024 * 2.4e9 / 2.0
             out["roofline_valu"] = {"bound": "valu", "kernel": kname, "achieved": round(prof["SQ_INSTS_VALU"] / t_prof / 1e9, 1), "peak": round(peak / 1e9, 1),
                                     "unit": "G wave-instructions/s", "frac": round(prof["SQ_INSTS_VALU"] / t_prof / peak, 4),
-                                    "how": "SQ_INSTS_VALU per launch / launch duration of the same rocprofv3 pass, against 1024 SIMDs x 2.4 GHz / 2 cycles"}
+                                    "how": "SQ_INSTS_VALU per launch / launch duration of the same rocprofv3 pass, against 1024 SIMDs x 2.4 GHz / 2 cycles",
+                                    "limits_the_kernel": roofline["bound"] == "valu"}
         return out
 
     def summary(o):
