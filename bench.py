@@ -928,6 +928,12 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
                                                       ograds, y0=sl.start, y1=sl.stop)
             except Exception as ex:
                 par["residual"] = {"error": repr(ex)[:200]}
+            try:
+                res = par.get("residual") or {}
+                if res.get("by") and res.get("explained", "0/1").split("/")[0] == res.get("explained", "0/1").split("/")[1]:
+                    res["nudged_oracle"] = nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, res["by"])
+            except Exception as ex:
+                par["residual"]["nudged_oracle"] = {"error": repr(ex)[:200]}
         for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
             if not ref.available(variant):
                 continue
@@ -960,6 +966,41 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
     except Exception as ex:  # the headline stands on its own
         par["vs_reference_error"] = repr(ex)[:300]
     return out
+
+
+def nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, by, budget_s=40.0):
+    """The explained residual, closed: the oracle re-run on the same window with the ONE kind of per-pixel threshold the explanation names moved by the
+    smallest amount that flips the decision (oracle.blend_nudge: at most 6e-7 on an alpha, 1e-6 on a transmittance -- the explanation's own bands), and the
+    product compared with THAT: a complete explanation leaves no pixel above 2e-6 and no gradient above 1e-4.  Checker-side only."""
+    from oracle import oracle as orc
+    kinds = [k for k in ("alpha_threshold", "subtile_cull", "T_threshold") if by.get(k)]
+    tries = []
+    for mag in (1e-9, 1e-8, 1e-7, 6e-7):
+        for sign in (1.0, -1.0):
+            if "alpha_threshold" in kinds:
+                tries.append({"alpha": sign * mag})
+            if "subtile_cull" in kinds:
+                tries.append({"cull_alpha": sign * mag})
+            if "T_threshold" in kinds:
+                tries.append({"T": sign * mag * (10.0 if mag < 6e-7 else 1.0 / 0.6)})
+    t0 = time.perf_counter()
+    best = None
+    for n, kw in enumerate(tries, 1):
+        with orc.blend_nudge(**kw):
+            f2 = orc.forward_scene(scene, sdict, tile_rows=(y0, y0 + nrows))
+            g2 = None if (fwd_only or gw is None) else f2.backward(scene.dL_dout)
+        rec = {"nudge": {k: float(v) for k, v in kw.items()}, "runs": n, **_img_err(img_p, f2.color[:, sl])}
+        if g2 is not None:
+            rec.update(_grad_err(gw, g2))
+        f2.free()
+        closed = rec["pixels_moved_gt_2e-6"] == 0 and not rec.get("gaussians_over_1e-4")
+        if best is None or closed or (rec["pixels_moved_gt_2e-6"], rec.get("gaussians_over_1e-4", 0)) < (best["pixels_moved_gt_2e-6"], best.get("gaussians_over_1e-4", 0)):
+            best = rec
+        if closed or time.perf_counter() - t0 > budget_s:
+            break
+    best["closes_the_residual"] = bool(best["pixels_moved_gt_2e-6"] == 0 and not best.get("gaussians_over_1e-4"))
+    best["what"] = "product vs the oracle with the named threshold moved by `nudge` on the same window: a decision on its threshold taken the other way, nothing else"
+    return best
 
 
 def cpu_baseline(scene, sdict, gy, fwd_only, rows):

@@ -6,6 +6,7 @@ Pinned against the reference's own sources compiled for gfx950 (oracle/ref_build
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
 import subprocess
@@ -219,6 +220,21 @@ def set_flag(name: str, value: int) -> None:
     L.orc_set_flag.argtypes = [ctypes.c_char_p, ctypes.c_int]
     L.orc_set_flag.restype = None
     L.orc_set_flag(name.encode(), int(value))
+
+
+@contextlib.contextmanager
+def blend_nudge(alpha: float = 0.0, T: float = 0.0, cull_alpha: float = 0.0):
+    """Inside the block the oracle's per-pixel blend decisions use thresholds moved by these amounts (alpha < 1/255 + alpha: skip; test_T < 1e-4 + T: stop;
+    the 4x4 sub-tile culling's alpha < 1/255 + cull_alpha): the checker's question "is this the reference's result with a decision that sits on its
+    threshold taken the other way?" (tests/test_gpu_parity.py).  Everything else -- preprocessing, tile culling, sorting -- is untouched."""
+    L = lib()
+    L.orc_set_blend_nudge.argtypes = [ctypes.c_float] * 3
+    L.orc_set_blend_nudge.restype = None
+    L.orc_set_blend_nudge(float(alpha), float(T), float(cull_alpha))
+    try:
+        yield
+    finally:
+        L.orc_set_blend_nudge(0.0, 0.0, 0.0)
 
 
 def num_threads() -> int:

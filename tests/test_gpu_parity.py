@@ -26,6 +26,45 @@ def _rel(a, b):
     return max_abs(a, b) / max(float(np.max(np.abs(b))), 1e-30) if np.size(b) else 0.0
 
 
+FLIP_STATS = {"flipped_frames": 0, "closed_by_nudge": 0}  # (tools/fuzz_parity.py prints them: how many frames with a decision on its threshold, how many the nudged oracle closed)
+
+
+def _matches_a_nudged_oracle(scene, sd, g, backward, img_tol, grad_tol, explained_by):
+    """A frame with an explained threshold decision: is the product's WHOLE output -- image to img_tol, every gradient tensor to grad_tol, the tolerances of a
+    frame without any such decision -- the oracle's with that decision taken the other way?  The oracle is re-run with its per-pixel thresholds moved by the
+    smallest amount that does it (oracle.blend_nudge: alpha 1/255, transmittance 1e-4, the sub-tile culling's alpha; at most the 6e-7 / 1e-6 bands of
+    oracle/explain.py, both directions).  True = yes, and the frame needs no looser tolerance at all; False = fall back to the flipped-frame tolerances
+    (several decisions in one frame that went different ways)."""
+    from oracle import oracle as orc
+    tries = []
+    for mag in (1e-9, 1e-8, 1e-7, 6e-7):
+        for sign in (1.0, -1.0):
+            tries.append(dict(alpha=sign * mag))
+            tries.append(dict(cull_alpha=sign * mag))
+    for mag in (1e-8, 1e-7, 1e-6):
+        for sign in (1.0, -1.0):
+            tries.append(dict(T=sign * mag))
+    for kw in tries:
+        with orc.blend_nudge(**kw):
+            f2, og2 = oracle_run(scene, sd, backward=backward)
+        if np.abs(g.color.astype(np.float64) - f2.color.astype(np.float64)).max() > img_tol:
+            continue
+        ok = True
+        if backward:
+            for k in GRAD_KEYS:
+                if g.grads.get(k) is None or og2.get(k) is None or og2[k].size == 0:
+                    continue
+                a, b = g.grads[k], og2[k]
+                if k == "dL_dmeans2D":
+                    a, b = a[:, :2], b[:, :2]
+                if not _rel(a, b) < grad_tol:
+                    ok = False
+                    break
+        if ok:
+            return True
+    return False
+
+
 def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-6, grad_tol=1e-4, flip_grad_tol=2e-3):
     """img_tol / grad_tol: the fixed test scenes blend tens of entries per pixel; tools/fuzz_parity.py --heavy (hundreds to
     a thousand blends per pixel, opacities at the 1/255 threshold) passes looser ones -- fp32 rounding accumulates with
@@ -53,6 +92,7 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-
     # fp32 exponent, exponential in double -- lies within 6e-7 of 1/255 at the pixel; with hierarchical_4x4_culling the same at its 4x4
     # sub-tile's point of maximum contribution (ONE decision there removes an entry from 16 pixels, ref: hierarchical_render.cuh:722-743); or a
     # final transmittance within 1e-6 of the 1e-4 threshold on either side.  No blanket allowance.
+    explained_by = None
     diff = np.abs(g.color.astype(np.float64) - f.color.astype(np.float64))
     assert diff.max() <= 1.0 / 255.0 + 1e-6
     moved = diff > img_tol
@@ -66,10 +106,16 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-
         if flipped:
             ex = probe(moved.any(axis=0))
             assert not ex["unexplained"], (flipped, ex["by"], ex["unexplained"][:5])
+            explained_by = ex["by"]
         elif probe((diff > 2e-6).any(axis=0))["explained"]:
             # a decision on its threshold that moved its pixel by less than img_tol (a faint Gaussian deep in a dense scene): the pixel passes as it is,
             # but that Gaussian's gradient still carries the whole blend -- the gradient tolerance of a flipped frame applies
             flipped = 1
+    if flipped:
+        FLIP_STATS["flipped_frames"] += 1
+        if _matches_a_nudged_oracle(scene, sd, g, backward, img_tol, grad_tol, explained_by):
+            FLIP_STATS["closed_by_nudge"] += 1
+            return g, f
     assert psnr(g.color, f.color) >= (100.0 if flipped == 0 else 75.0)  # (one flipped pixel of a 1600-pixel image: 80 dB)
     # a flipped blend also changes that Gaussian's (and, through the transmittance, its pixel's later Gaussians') gradient
     # terms by the weight of one pixel: 1e-4 of the largest entry when no blend flipped, 2e-3 otherwise

@@ -207,3 +207,32 @@ def test_render_depth_visualisation_oracle():
     assert empty.any()
     top = np.array([0.47960, 0.01583, 0.01055], np.float32).reshape(3, 1)  # last entry of the Turbo table
     assert np.allclose(imgs[1][:, empty], top, atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", [0, 2, 3])
+def test_blend_nudge_moves_only_the_blend_decisions_and_resets(mode):
+    """The checker's knob (oracle.blend_nudge, used by check_against_oracle for frames with a decision on its threshold): a large nudge changes the image,
+    never the state in front of the blend loop; a nudge far below the distance of any decision from its threshold changes nothing; leaving the block restores
+    the reference's constants."""
+    sc = scenes.make_scene(P=1500, W=96, H=64, sigma_min=1.5, sigma_max=9.0, seed=21, camera="orbit", opacity_range=(0.004, 0.3))
+    sd = settings_dict(mode, per_pixel=4 if mode == 3 else 8)
+    base = orc.forward_scene(sc, sd)
+    gb = base.backward(sc.dL_dout)
+    with orc.blend_nudge(alpha=2e-3):
+        big = orc.forward_scene(sc, sd)
+    assert big.num_rendered == base.num_rendered
+    for nm in ("keys", "point_list", "ranges", "conic_opacity", "means2D"):
+        assert np.array_equal(big.array(nm), base.array(nm)), nm
+    assert not np.array_equal(big.color, base.color)       # alphas between 1/255 and 1/255 + 2e-3 no longer blend
+    assert float(big.color.sum()) < float(base.color.sum())  # (black background: fewer blends, less light)
+    with orc.blend_nudge(T=0.5):
+        early = orc.forward_scene(sc, sd)                   # pixels stop at half transmittance
+    assert float(early.array("final_T").min()) >= 0.5 - 1e-6
+    with orc.blend_nudge(alpha=1e-12, T=1e-12):
+        tiny = orc.forward_scene(sc, sd)                    # (1/255 + 1e-12 == 1/255 in fp32)
+    assert np.array_equal(tiny.color, base.color)
+    again = orc.forward_scene(sc, sd)
+    ga = again.backward(sc.dL_dout)
+    assert np.array_equal(again.color, base.color)
+    for k in gb:
+        assert np.array_equal(ga[k], gb[k]), k

@@ -116,7 +116,9 @@ def main():
                 print(f"   sh_degree={scene.sh_degree} scale_modifier={scene.scale_modifier}")
                 print("   " + "\n   ".join(traceback.format_exc().splitlines()[-14:]), flush=True)
         done += 1
-    print(f"fuzz: {done} cases, {bad} failures, {time.time() - t0:.0f} s")
+    import test_gpu_parity as tgp
+    print(f"fuzz: {done} cases, {bad} failures, {time.time() - t0:.0f} s; frames with a blend decision on its threshold: {tgp.FLIP_STATS['flipped_frames']}, "
+          f"of which the oracle with that threshold nudged reproduces the product to the plain tolerances: {tgp.FLIP_STATS['closed_by_nudge']}")
     sys.exit(1 if bad else 0)
 
 
