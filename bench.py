@@ -440,6 +440,7 @@ def explain_differences(prod, other_color, other_final_T, other_grads=None, y0=0
     ex = explain.explain_moved_pixels(moved, W=W, H=H, ranges=st["ranges"], point_list=st["point_list"], conic_opacity=st["conic_opacity"],
                                       means2D=st["means2D"], final_T_a=st["final_T"], final_T_b=other_final_T, cull_4x4=st["cull_4x4"])
     out = {"pixels_moved_gt_2e-6": ex["pixels"], "explained": f"{ex['explained']}/{ex['pixels']}", "by": {k: v for k, v in ex["by"].items() if v},
+           "decisions": [list(d) for d in ex["decisions"][:16]],
            "criterion": "an entry's alpha (fp32 exponent, exp in double) within 6e-7 of 1/255 at the pixel or at its 4x4 sub-tile's culling point, or a final T within 1e-6 of 1e-4"}
     if ex["unexplained"]:
         out["unexplained_pixels"] = ex["unexplained"][:8]
@@ -931,7 +932,7 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
             try:
                 res = par.get("residual") or {}
                 if res.get("by") and res.get("explained", "0/1").split("/")[0] == res.get("explained", "0/1").split("/")[1]:
-                    res["nudged_oracle"] = nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, res["by"])
+                    res["nudged_oracle"] = nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, {"by": res["by"], "decisions": [tuple(d) for d in res.get("decisions", [])]})
             except Exception as ex:
                 par["residual"]["nudged_oracle"] = {"error": repr(ex)[:200]}
         for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
@@ -968,28 +969,33 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
     return out
 
 
-def nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, by, budget_s=40.0):
-    """The explained residual, closed: the oracle re-run on the same window with the ONE kind of per-pixel threshold the explanation names moved by the
-    smallest amount that flips the decision (oracle.blend_nudge: at most 6e-7 on an alpha, 1e-6 on a transmittance -- the explanation's own bands), and the
-    product compared with THAT: a complete explanation leaves no pixel above 2e-6 and no gradient above 1e-4.  Checker-side only."""
+def nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, ex, budget_s=40.0):
+    """The explained residual, closed: the oracle re-run on the same window with exactly the per-pixel alpha tests the explanation names taken the other way
+    (oracle.forced_alpha_flips) -- or, for the other kinds of decision, with that kind's threshold moved inside the explanation's own band (oracle.blend_nudge) --
+    and the product compared with THAT: a complete explanation leaves no pixel above 2e-6 and no gradient above 1e-4.  Checker-side only."""
     from oracle import oracle as orc
-    kinds = [k for k in ("alpha_threshold", "subtile_cull", "T_threshold") if by.get(k)]
+    by = ex["by"]
     tries = []
-    for mag in (1e-9, 1e-8, 1e-7, 6e-7):
+    if ex.get("decisions"):
+        tries.append(({"forced_alpha_flips": [list(d) for d in ex["decisions"][:16]]}, lambda: orc.forced_alpha_flips(ex["decisions"], scene.W)))
+    for frac in (0.1, 0.25, 0.5, 1.0):
         for sign in (1.0, -1.0):
-            if "alpha_threshold" in kinds:
-                tries.append({"alpha": sign * mag})
-            if "subtile_cull" in kinds:
-                tries.append({"cull_alpha": sign * mag})
-            if "T_threshold" in kinds:
-                tries.append({"T": sign * mag * (10.0 if mag < 6e-7 else 1.0 / 0.6)})
+            if by.get("alpha_threshold") and not ex.get("decisions"):
+                v = sign * frac * 6e-7 / 255.0
+                tries.append(({"alpha": v}, lambda v=v: orc.blend_nudge(alpha=v)))
+            if by.get("subtile_cull"):
+                v = sign * frac * 6e-7 / 255.0
+                tries.append(({"cull_alpha": v}, lambda v=v: orc.blend_nudge(cull_alpha=v)))
+            if by.get("T_threshold"):
+                v = sign * frac * 1e-6 * 1e-4
+                tries.append(({"T": v}, lambda v=v: orc.blend_nudge(T=v)))
     t0 = time.perf_counter()
     best = None
-    for n, kw in enumerate(tries, 1):
-        with orc.blend_nudge(**kw):
+    for n, (what, ctx) in enumerate(tries, 1):
+        with ctx():
             f2 = orc.forward_scene(scene, sdict, tile_rows=(y0, y0 + nrows))
             g2 = None if (fwd_only or gw is None) else f2.backward(scene.dL_dout)
-        rec = {"nudge": {k: float(v) for k, v in kw.items()}, "runs": n, **_img_err(img_p, f2.color[:, sl])}
+        rec = {"oracle_run_with": what, "runs": n, **_img_err(img_p, f2.color[:, sl])}
         if g2 is not None:
             rec.update(_grad_err(gw, g2))
         f2.free()
@@ -998,8 +1004,10 @@ def nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, by, bu
             best = rec
         if closed or time.perf_counter() - t0 > budget_s:
             break
+    if best is None:
+        return {"note": "no decision of a kind the oracle can take the other way"}
     best["closes_the_residual"] = bool(best["pixels_moved_gt_2e-6"] == 0 and not best.get("gaussians_over_1e-4"))
-    best["what"] = "product vs the oracle with the named threshold moved by `nudge` on the same window: a decision on its threshold taken the other way, nothing else"
+    best["what"] = "product vs the oracle re-run on the same window with the explained decision(s) taken the other way and nothing else changed"
     return best
 
 

@@ -85,10 +85,12 @@ def explain_moved_pixels(moved, *, W, H, ranges, point_list, conic_opacity, mean
     """moved: (H, W) bool -- pixels that differ between two renderings of the same frame.  Every other array is shared by the two sides bit for
     bit (flat numpy arrays in the layouts of the oracle / the reference: ranges 2 per tile, conic_opacity 4 per Gaussian, means2D 2 per
     Gaussian); final_T_a / final_T_b: the two sides' final transmittance (H * W), when they are at hand.
-    Returns {"pixels": n, "explained": m, "by": {...}, "unexplained": [(x, y), ...], "gaussians": ids blended at an explained pixel}."""
+    Returns {"pixels": n, "explained": m, "by": {...}, "unexplained": [(x, y), ...], "gaussians": ids blended at an explained pixel,
+    "decisions": [(x, y, gaussian id), ...] the alpha test nearest 1/255 at every pixel explained by one (oracle.forced_alpha_flips takes them)}."""
     gx = (W + 15) // 16
     ys, xs = np.nonzero(moved)
-    out = {"pixels": int(ys.size), "explained": 0, "by": {"alpha_threshold": 0, "subtile_cull": 0, "T_threshold": 0}, "unexplained": [], "gaussians": set()}
+    out = {"pixels": int(ys.size), "explained": 0, "by": {"alpha_threshold": 0, "subtile_cull": 0, "T_threshold": 0}, "unexplained": [], "gaussians": set(),
+           "decisions": []}  # decisions: (x, y, gaussian id) of the per-pixel alpha test nearest its threshold at every pixel explained that way
     cull_cache = {}
     for y, x in list(zip(ys.tolist(), xs.tolist()))[:limit]:
         ids = _entries(ranges, point_list, gx, x, y)
@@ -98,6 +100,7 @@ def explain_moved_pixels(moved, *, W, H, ranges, point_list, conic_opacity, mean
             near = np.abs(a * 255.0 - 1.0) <= ALPHA_TOL
             if near.any():
                 why = "alpha_threshold"
+                out["decisions"].append((int(x), int(y), int(ids[int(np.argmin(np.abs(a * 255.0 - 1.0)))])))
                 out["gaussians"].update(ids[a >= _THR * (1.0 - ALPHA_TOL)].tolist())
             if why is None and cull_4x4:
                 key = (x // 4, y // 4)

@@ -237,5 +237,20 @@ def blend_nudge(alpha: float = 0.0, T: float = 0.0, cull_alpha: float = 0.0):
         L.orc_set_blend_nudge(0.0, 0.0, 0.0)
 
 
+@contextlib.contextmanager
+def forced_alpha_flips(decisions, W: int):
+    """Inside the block the oracle takes the per-pixel alpha test of every (x, y, gaussian_id) in `decisions` the OTHER way (blends what it would skip,
+    skips what it would blend) and nothing else differently: the exact form of blend_nudge for one decision that sits on its threshold."""
+    L = lib()
+    L.orc_set_forced_alpha_flips.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    L.orc_set_forced_alpha_flips.restype = None
+    keys = np.ascontiguousarray([((int(y) * int(W) + int(x)) << 32) | (int(g) & 0xFFFFFFFF) for x, y, g in decisions], dtype=np.uint64)
+    L.orc_set_forced_alpha_flips(int(keys.size), keys.ctypes.data_as(ctypes.c_void_p))
+    try:
+        yield
+    finally:
+        L.orc_set_forced_alpha_flips(0, None)
+
+
 def num_threads() -> int:
     return int(lib().orc_num_threads())

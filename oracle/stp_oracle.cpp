@@ -43,6 +43,18 @@ constexpr float T_THRESHOLD = 0.0001f;
 // "is the product's output the reference algorithm's with a decision that sits ON its threshold taken the other way?" -- tests/test_gpu_parity.py,
 // check_against_oracle.  The defaults are the reference's constants; preprocessing and tile culling never look at these.
 static float g_blend_alpha_thr = ALPHA_THRESHOLD, g_blend_T_thr = T_THRESHOLD, g_cull_alpha_thr = ALPHA_THRESHOLD; // (the last one: the 4x4 sub-tile culling's own alpha test)
+// ... and single decisions taken the other way: (pixel index << 32 | Gaussian id) of per-pixel alpha tests whose outcome is inverted (orc_set_forced_alpha_flips,
+// sorted) -- a whole frame has dozens of alphas within any band around 1/255, moving the threshold for all of them is too blunt there
+static std::vector<uint64_t> g_forced_alpha;
+static inline bool alpha_skips(float alpha, int W, int px, int py, int id)
+{
+    bool skip = alpha < g_blend_alpha_thr;
+    if (!g_forced_alpha.empty()) {
+        const uint64_t key = ((uint64_t)((size_t)py * (size_t)W + (size_t)px) << 32) | (uint64_t)(uint32_t)id;
+        if (std::binary_search(g_forced_alpha.begin(), g_forced_alpha.end(), key)) skip = !skip;
+    }
+    return skip;
+}
 constexpr uint32_t INVALID_TILE = 0xFFFFFFFFu;
 
 constexpr float SH_C0 = 0.28209479177387814f;
@@ -645,7 +657,7 @@ inline bool eval_alpha(const OrcFrame& f, int id, int px, int py, float& G, floa
     if (power > 0.0f) return false;
     G = expf(power);
     alpha = std::min(0.99f, co[3] * G);
-    if (alpha < g_blend_alpha_thr) return false;
+    if (alpha_skips(alpha, f.W, px, py, id)) return false;
     return true;
 }
 
@@ -722,7 +734,7 @@ void render_global_bwd(const OrcFrame& f, const RenderCtx& c, GradAcc& g, const 
                     if (power > 0.0f) continue;
                     const float G = expf(power);
                     const float alpha = std::min(0.99f, co[3] * G);
-                    if (alpha < g_blend_alpha_thr) continue;
+                    if (alpha_skips(alpha, f.W, px, py, id)) continue;
                     T = T / (1.f - alpha);
                     const float dchannel_dcolor = alpha * T;
                     float dL_dalpha = 0.0f;
@@ -1156,7 +1168,7 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                         const float power = opacity_factor(dx, dy, co); // positive form (ref: resorted_render.cuh:621-630)
                         if (power < 0.0f) continue;
                         const float alpha = std::min(0.99f, co[3] * expf(-power));
-                        if (alpha < g_blend_alpha_thr) continue;
+                        if (alpha_skips(alpha, f.W, px, py, id)) continue;
                         const float test_T = T * (1 - alpha);
                         if (test_T < g_blend_T_thr) { done = true; break; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)id + ch] * alpha * T;
@@ -1586,6 +1598,12 @@ void orc_set_blend_nudge(float alpha_delta, float T_delta, float cull_alpha_delt
     g_blend_alpha_thr = ALPHA_THRESHOLD + alpha_delta;
     g_blend_T_thr = T_THRESHOLD + T_delta;
     g_cull_alpha_thr = ALPHA_THRESHOLD + cull_alpha_delta;
+}
+
+void orc_set_forced_alpha_flips(int n, const uint64_t* keys) // n = 0: none
+{
+    g_forced_alpha.assign(keys, keys + (n > 0 ? n : 0));
+    std::sort(g_forced_alpha.begin(), g_forced_alpha.end());
 }
 
 int orc_num_threads(void)

@@ -29,23 +29,24 @@ def _rel(a, b):
 FLIP_STATS = {"flipped_frames": 0, "closed_by_nudge": 0}  # (tools/fuzz_parity.py prints them: how many frames with a decision on its threshold, how many the nudged oracle closed)
 
 
-def _matches_a_nudged_oracle(scene, sd, g, backward, img_tol, grad_tol, explained_by):
+def _matches_a_nudged_oracle(scene, sd, g, backward, img_tol, grad_tol, ex):
     """A frame with an explained threshold decision: is the product's WHOLE output -- image to img_tol, every gradient tensor to grad_tol, the tolerances of a
-    frame without any such decision -- the oracle's with that decision taken the other way?  The oracle is re-run with its per-pixel thresholds moved by the
-    smallest amount that does it (oracle.blend_nudge: alpha 1/255, transmittance 1e-4, the sub-tile culling's alpha; at most the 6e-7 / 1e-6 bands of
-    oracle/explain.py, both directions).  True = yes, and the frame needs no looser tolerance at all; False = fall back to the flipped-frame tolerances
-    (several decisions in one frame that went different ways)."""
+    frame without any such decision -- the oracle's with that decision taken the other way?  The oracle is re-run (a) with exactly the alpha tests the
+    explanation names inverted (oracle.forced_alpha_flips), then (b) with one of its per-pixel thresholds moved inside the explanation's own band
+    (oracle.blend_nudge: 1/255 (1 +- 6e-7), 1e-4 (1 +- 1e-6), the sub-tile culling's alpha; both directions, smallest first).  True = yes, and the frame
+    needs no looser tolerance at all; False = fall back to the flipped-frame tolerances (decisions of several kinds, or a pixel with two alphas in the band)."""
+    import contextlib
     from oracle import oracle as orc
     tries = []
-    for mag in (1e-9, 1e-8, 1e-7, 6e-7):
+    if ex and ex.get("decisions"):
+        tries.append(lambda: orc.forced_alpha_flips(ex["decisions"], scene.W))
+    for frac in (0.1, 0.25, 0.5, 1.0):
         for sign in (1.0, -1.0):
-            tries.append(dict(alpha=sign * mag))
-            tries.append(dict(cull_alpha=sign * mag))
-    for mag in (1e-8, 1e-7, 1e-6):
-        for sign in (1.0, -1.0):
-            tries.append(dict(T=sign * mag))
-    for kw in tries:
-        with orc.blend_nudge(**kw):
+            tries.append(lambda v=sign * frac * 6e-7 / 255.0: orc.blend_nudge(alpha=v))
+            tries.append(lambda v=sign * frac * 6e-7 / 255.0: orc.blend_nudge(cull_alpha=v))
+            tries.append(lambda v=sign * frac * 1e-6 * 1e-4: orc.blend_nudge(T=v))
+    for ctx in tries:
+        with ctx():
             f2, og2 = oracle_run(scene, sd, backward=backward)
         if np.abs(g.color.astype(np.float64) - f2.color.astype(np.float64)).max() > img_tol:
             continue
@@ -106,8 +107,9 @@ def check_against_oracle(scene, sd, backward=True, exact_state=True, img_tol=2e-
         if flipped:
             ex = probe(moved.any(axis=0))
             assert not ex["unexplained"], (flipped, ex["by"], ex["unexplained"][:5])
-            explained_by = ex["by"]
-        elif probe((diff > 2e-6).any(axis=0))["explained"]:
+            explained_by = ex
+        elif (ex2 := probe((diff > 2e-6).any(axis=0)))["explained"]:
+            explained_by = ex2
             # a decision on its threshold that moved its pixel by less than img_tol (a faint Gaussian deep in a dense scene): the pixel passes as it is,
             # but that Gaussian's gradient still carries the whole blend -- the gradient tolerance of a flipped frame applies
             flipped = 1

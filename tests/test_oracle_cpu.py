@@ -236,3 +236,30 @@ def test_blend_nudge_moves_only_the_blend_decisions_and_resets(mode):
     assert np.array_equal(again.color, base.color)
     for k in gb:
         assert np.array_equal(ga[k], gb[k]), k
+
+
+def test_forced_alpha_flip_changes_one_pixel_and_resets():
+    """oracle.forced_alpha_flips: ONE per-pixel alpha test taken the other way moves that pixel and no other; a Gaussian's gradient changes only if it is
+    blended there; leaving the block restores the oracle."""
+    from oracle import explain
+    sc = scenes.make_scene(P=600, W=64, H=48, sigma_min=2.0, sigma_max=8.0, seed=5, camera="orbit")
+    sd = settings_dict(0)
+    base = orc.forward_scene(sc, sd)
+    gb = base.backward(sc.dL_dout)
+    x, y = 30, 20
+    ids = explain._entries(base.array("ranges").reshape(-1), base.array("point_list"), (sc.W + 15) // 16, x, y)
+    a = explain.pixel_alphas(ids, base.array("conic_opacity").reshape(-1), base.array("means2D").reshape(-1), x, y)
+    blended = ids[a > 0.05]
+    assert blended.size, "pick another pixel: nothing blends visibly here"
+    gid = int(blended[0])
+    with orc.forced_alpha_flips([(x, y, gid)], sc.W):
+        f2 = orc.forward_scene(sc, sd)
+        g2 = f2.backward(sc.dL_dout)
+    d = np.abs(f2.color - base.color).max(axis=0)
+    assert d[y, x] > 1e-4
+    d[y, x] = 0.0
+    assert d.max() == 0.0
+    changed = np.nonzero(np.abs(g2["dL_dopacity"] - gb["dL_dopacity"]).reshape(sc.P, -1).max(axis=1) > 0)[0]
+    assert set(changed.tolist()) <= set(ids.tolist()) and gid in changed
+    again = orc.forward_scene(sc, sd)
+    assert np.array_equal(again.color, base.color)
