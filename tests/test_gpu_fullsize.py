@@ -48,11 +48,26 @@ def test_full_size_tile_rows_against_oracle(name):
     assert np.array_equal(g.binning_array("point_list"), f.array("point_list"))
     sl = slice(rows[0] * 16, min(rows[1] * 16, sc.H))
     d = np.abs(g.color[:, sl].astype(np.float64) - f.color[:, sl].astype(np.float64))
-    # 1000+ blends per pixel in C3 / C5: fp32 rounding accumulates (3e-6), and an alpha on the 1/255 threshold may flip
-    flipped = int((d > 4e-6).sum())
-    assert d.max() <= 1.0 / 255.0 + 1e-6 and flipped <= max(6, int(2e-5 * d.size)), (d.max(), flipped)
+    # 1000+ blends per pixel in C3 / C5: fp32 rounding accumulates (3e-6).  A pixel beyond that moved because a decision of the blend loop sits on its
+    # threshold -- it has to be EXPLAINED (oracle/explain.py, as in test_gpu_parity.check_against_oracle: no allowance by count), and the window then has to
+    # match the oracle re-run with that decision taken the other way at the plain tolerances; only a window that mixes several decisions falls back to 2e-3
+    IMG_TOL = 4e-6
+    assert d.max() <= 1.0 / 255.0 + 1e-6
+    moved = np.zeros((sc.H, sc.W), bool)
+    moved[sl] = (d > IMG_TOL).any(axis=0)
+    flipped = int(moved.sum())
+    closed = False
+    if flipped:
+        from oracle import explain
+        from test_gpu_parity import _matches_a_nudged_oracle
+        ex = explain.explain_moved_pixels(moved, W=sc.W, H=sc.H, ranges=f.array("ranges").reshape(-1), point_list=f.array("point_list"),
+                                          conic_opacity=f.array("conic_opacity").reshape(-1), means2D=f.array("means2D").reshape(-1),
+                                          final_T_a=g.image_array("final_T").reshape(-1), final_T_b=f.array("final_T").reshape(-1),
+                                          cull_4x4=bool(sd["culling_settings"]["hierarchical_4x4_culling"]) and sd["sort_settings"]["sort_mode"] == 3)
+        assert not ex["unexplained"], (flipped, ex["by"], ex["unexplained"][:5])
+        closed = _matches_a_nudged_oracle(sc, sd, g, backward, IMG_TOL, 1e-4, ex, tile_rows=rows, max_tries=7)
     assert psnr(g.color[:, sl], f.color[:, sl]) >= (100.0 if flipped == 0 else 75.0)
-    if backward:
+    if backward and not closed:
         tol = 1e-4 if flipped == 0 else 2e-3
         for k in ("dL_dmeans3D", "dL_dopacity", "dL_dscales", "dL_drotations", "dL_dsh", "dL_dmeans2D"):
             a, b = g.grads[k], og[k]
