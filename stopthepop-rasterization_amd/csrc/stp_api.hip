@@ -833,7 +833,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
     bool colour_started = !(side && colour_late);
     auto binning_and_render = [&](const GeometryState& gd, const BinningState& b, int L, uint32_t dup_cap) -> int {
         uint32_t* zero_ptr = nullptr; size_t zero_words = 0; // (the tile-bit sort's histograms / look-back states / block counters: cleared here, once)
-        if (!atomic_bin && tile_local_sort) sort_zero_region(b, (size_t)L, &zero_ptr, &zero_words);
+        if (!atomic_bin && tile_local_sort) sort_zero_region(b, (size_t)L, (uint32_t)(f.gx * f.gy), &zero_ptr, &zero_words);
         STP_TRY(launch_duplicate(f, gd, radii, b, atomic_bin ? img.tile_cursor : nullptr, dup_cap, (uint32_t)L, zero_ptr, zero_words, st), "duplicate launch");
         STP_DEBUG_SYNC("duplicate");
         g_timer.mark(2, st);

@@ -86,12 +86,12 @@ using OsBlockId = rpd::block_id_wrapper<unsigned int, true>;
 
 struct OsLayout { // inside BinningState::sort_temp
     uint32_t* offsets;                                  // [places][radix] digit histograms -> exclusive offsets   } zeroed once per frame
-    rpd::onesweep_lookback_state* lookback;             // [places][radix * blocks]                                   } (sort_zero)
-    unsigned int* block_ids;                            // [places]                                                   }
+    unsigned int* block_ids;                            // [places]                                                   } (sort_zero)
+    rpd::onesweep_lookback_state* lookback;             // [places][radix * blocks]                                   }
     uint32_t* offsets_tmp;                              // [radix] (next-batch offsets: written, never read with one batch)
     uint64_t* keys_tmp;                                 // [R]
     uint32_t* values_tmp;                               // [R]
-    size_t zero_bytes, total;
+    size_t zero_bytes, total, lookback_offset;          // zero_bytes: all places' states; a frame clears [0, lookback_offset + its places' states)
     uint32_t sort_blocks;
 };
 OsLayout os_layout(char* base, size_t R)
@@ -100,9 +100,12 @@ OsLayout os_layout(char* base, size_t R)
     auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
     L.sort_blocks = (uint32_t)((R + OS_SORT_ITEMS - 1) / OS_SORT_ITEMS);
     size_t off = 0;
+    // (the look-back states last: a frame's sort uses the first `places` of them -- two at 1080p -- and only those are cleared, sort_zero_region)
     L.offsets = reinterpret_cast<uint32_t*>(base + off); off += up(sizeof(uint32_t) * OS_MAX_PLACES * OS_RADIX);
-    L.lookback = reinterpret_cast<rpd::onesweep_lookback_state*>(base + off); off += up(sizeof(rpd::onesweep_lookback_state) * OS_MAX_PLACES * OS_RADIX * (size_t)L.sort_blocks);
     L.block_ids = reinterpret_cast<unsigned int*>(base + off); off += up(sizeof(unsigned int) * OS_MAX_PLACES);
+    L.lookback = reinterpret_cast<rpd::onesweep_lookback_state*>(base + off);
+    L.lookback_offset = off;
+    off += up(sizeof(rpd::onesweep_lookback_state) * OS_MAX_PLACES * OS_RADIX * (size_t)L.sort_blocks);
     L.zero_bytes = off;
     L.offsets_tmp = reinterpret_cast<uint32_t*>(base + off); off += up(sizeof(uint32_t) * OS_RADIX);
     L.keys_tmp = reinterpret_cast<uint64_t*>(base + off); off += up(sizeof(uint64_t) * R);
@@ -152,13 +155,16 @@ size_t sort_temp_bytes(size_t R)
 }
 
 // what duplicate_kernel's trailing workgroups clear in front of the tile-bit sort (nothing with the library's own driver)
-void sort_zero_region(const BinningState& b, size_t R, uint32_t** ptr, size_t* words)
+void sort_zero_region(const BinningState& b, size_t R, uint32_t tiles, uint32_t** ptr, size_t* words)
 {
     *ptr = nullptr; *words = 0;
     if (!own_onesweep_driver(R)) return;
     const OsLayout L = os_layout(b.sort_temp, R);
+    const uint32_t bit = higher_msb(tiles);
+    const size_t places = (bit + OS.radix_bits_per_place - 1) / OS.radix_bits_per_place; // (what launch_sort will run: two at 1080p, of OS_MAX_PLACES)
+    const size_t bytes = L.lookback_offset + ((sizeof(rpd::onesweep_lookback_state) * places * OS_RADIX * (size_t)L.sort_blocks + 255) & ~(size_t)255);
     *ptr = reinterpret_cast<uint32_t*>(b.sort_temp);
-    *words = L.zero_bytes / sizeof(uint32_t);
+    *words = (bytes < L.zero_bytes ? bytes : L.zero_bytes) / sizeof(uint32_t);
 }
 
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st)

@@ -181,7 +181,7 @@ hipError_t launch_duplicate(const FrameParams& f, const GeometryState& g, const 
 hipError_t launch_tile_scan(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_bin_pad(const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool tile_bits_only, bool zeroed, hipStream_t st); // zeroed: duplicate_kernel cleared sort_zero_region()
-void sort_zero_region(const BinningState& b, size_t R, uint32_t** ptr, size_t* words); // what the tile-bit sort's own driver needs cleared in front of it
+void sort_zero_region(const BinningState& b, size_t R, uint32_t tiles, uint32_t** ptr, size_t* words); // what the tile-bit sort's own driver needs cleared in front of it
 hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g, const BinningState& b, const ImageState& img, int R, bool unordered, hipStream_t st);
 hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const ImageState& img, int R, hipStream_t st);
 hipError_t launch_gather_entries(const FrameParams& f, const GeometryState& g, const BinningState& b, int R, hipStream_t st);
