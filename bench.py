@@ -440,7 +440,7 @@ def explain_differences(prod, other_color, other_final_T, other_grads=None, y0=0
     ex = explain.explain_moved_pixels(moved, W=W, H=H, ranges=st["ranges"], point_list=st["point_list"], conic_opacity=st["conic_opacity"],
                                       means2D=st["means2D"], final_T_a=st["final_T"], final_T_b=other_final_T, cull_4x4=st["cull_4x4"])
     out = {"pixels_moved_gt_2e-6": ex["pixels"], "explained": f"{ex['explained']}/{ex['pixels']}", "by": {k: v for k, v in ex["by"].items() if v},
-           "decisions": [list(d) for d in ex["decisions"][:16]],
+           "decisions": [list(d) for d in ex["decisions"][:16]], "T_pixels": [list(d) for d in ex["T_pixels"][:16]],
            "criterion": "an entry's alpha (fp32 exponent, exp in double) within 6e-7 of 1/255 at the pixel or at its 4x4 sub-tile's culling point, or a final T within 1e-6 of 1e-4"}
     if ex["unexplained"]:
         out["unexplained_pixels"] = ex["unexplained"][:8]
@@ -504,6 +504,31 @@ class ReferenceFrame:
             self.rf = None
 
 
+def forced_oracle_closure(scene, sdict, fwd_only, prod, res):
+    """A whole-frame residual against the reference whose every moved pixel is explained by a per-pixel alpha or transmittance decision on its threshold: the CPU oracle
+    is run ONCE on the whole frame with exactly those decisions taken the other way (oracle.forced_alpha_flips) and the product compared with it -- a complete
+    explanation leaves no pixel above 2e-6 and no gradient above 1e-4.  Checker-side only; None when there is nothing of that kind to force."""
+    from oracle import oracle as orc
+    by = res.get("by") or {}
+    dec = [tuple(d) for d in res.get("decisions", [])]
+    tpx = [tuple(d) for d in res.get("T_pixels", [])]
+    n_moved = int(res.get("pixels_moved_gt_2e-6", 0))
+    if not (dec or tpx) or by.get("subtile_cull") or res.get("explained") != f"{n_moved}/{n_moved}" or n_moved > 16:
+        return None
+    t0 = time.perf_counter()
+    with orc.forced_alpha_flips(dec, scene.W, T_pixels=tpx):
+        f2 = orc.forward_scene(scene, sdict)
+        g2 = None if (fwd_only or prod.get("grads") is None) else f2.backward(scene.dL_dout)
+    rec = {"oracle_run_with": {"forced_alpha_flips": [list(d) for d in dec], "forced_T_flips": [list(d) for d in tpx]}, **_img_err(prod["color"], f2.color)}
+    if g2 is not None:
+        rec.update(_grad_err(prod["grads"], g2))
+    f2.free()
+    rec["closes_the_residual"] = bool(rec["pixels_moved_gt_2e-6"] == 0 and not rec.get("gaussians_over_1e-4"))
+    rec["oracle_seconds"] = round(time.perf_counter() - t0, 1)
+    rec["what"] = "product vs the CPU oracle run on the whole frame with the explained decision(s) taken the other way and nothing else changed"
+    return rec
+
+
 def reference_parity(wl, dev, timing_steps=10, timing_warmup=3, with_fma=True, time_fma=True):
     """Whole-frame parity of one workload against the reference's IEEE build, for the default library and for the second shipped
     library (libstp_raster_fma.so), and the latter's speed in the same harness.  Returns {} when oracle/_ref is absent."""
@@ -529,6 +554,14 @@ def reference_parity(wl, dev, timing_steps=10, timing_warmup=3, with_fma=True, t
             out["vs_reference_ieee_build"]["as_configured"] = {k: first[k] for k in first if k != "build"}
         else:
             out["vs_reference_ieee_build"] = first
+        try:   # the residual, closed (see forced_oracle_closure)
+            res = out["vs_reference_ieee_build"].get("residual")
+            if isinstance(res, dict) and "error" not in res:
+                closure = forced_oracle_closure(wl.scene, wl.sdict, wl.fwd_only, prod, res)
+                if closure is not None:
+                    res["forced_oracle"] = closure
+        except Exception as ex:
+            out["vs_reference_ieee_build"]["residual"]["forced_oracle"] = {"error": repr(ex)[:200]}
         fma = os.path.join(os.path.dirname(_C.library_path()), FMA_LIB_NAME)
         if with_fma and os.path.exists(fma) and os.path.basename(_C.library_path()) != FMA_LIB_NAME:
             _C.use_library(fma)
@@ -932,7 +965,7 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
             try:
                 res = par.get("residual") or {}
                 if res.get("by") and res.get("explained", "0/1").split("/")[0] == res.get("explained", "0/1").split("/")[1]:
-                    res["nudged_oracle"] = nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, {"by": res["by"], "decisions": [tuple(d) for d in res.get("decisions", [])]})
+                    res["nudged_oracle"] = nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, {"by": res["by"], "decisions": [tuple(d) for d in res.get("decisions", [])], "T_pixels": [tuple(d) for d in res.get("T_pixels", [])]})
             except Exception as ex:
                 par["residual"]["nudged_oracle"] = {"error": repr(ex)[:200]}
         for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
@@ -976,8 +1009,9 @@ def nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, ex, bu
     from oracle import oracle as orc
     by = ex["by"]
     tries = []
-    if ex.get("decisions"):
-        tries.append(({"forced_alpha_flips": [list(d) for d in ex["decisions"][:16]]}, lambda: orc.forced_alpha_flips(ex["decisions"], scene.W)))
+    if ex.get("decisions") or ex.get("T_pixels"):
+        tries.append(({"forced_alpha_flips": [list(d) for d in ex.get("decisions", [])[:16]], "forced_T_flips": [list(d) for d in ex.get("T_pixels", [])[:16]]},
+                      lambda: orc.forced_alpha_flips(ex.get("decisions", []), scene.W, T_pixels=ex.get("T_pixels", []))))
     for frac in (0.1, 0.25, 0.5, 1.0):
         for sign in (1.0, -1.0):
             if by.get("alpha_threshold") and not ex.get("decisions"):
@@ -986,7 +1020,7 @@ def nudged_oracle_check(scene, sdict, fwd_only, y0, nrows, sl, img_p, gw, ex, bu
             if by.get("subtile_cull"):
                 v = sign * frac * 6e-7 / 255.0
                 tries.append(({"cull_alpha": v}, lambda v=v: orc.blend_nudge(cull_alpha=v)))
-            if by.get("T_threshold"):
+            if by.get("T_threshold") and not ex.get("T_pixels"):
                 v = sign * frac * 1e-6 * 1e-4
                 tries.append(({"T": v}, lambda v=v: orc.blend_nudge(T=v)))
     t0 = time.perf_counter()

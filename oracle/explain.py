@@ -86,11 +86,12 @@ def explain_moved_pixels(moved, *, W, H, ranges, point_list, conic_opacity, mean
     bit (flat numpy arrays in the layouts of the oracle / the reference: ranges 2 per tile, conic_opacity 4 per Gaussian, means2D 2 per
     Gaussian); final_T_a / final_T_b: the two sides' final transmittance (H * W), when they are at hand.
     Returns {"pixels": n, "explained": m, "by": {...}, "unexplained": [(x, y), ...], "gaussians": ids blended at an explained pixel,
-    "decisions": [(x, y, gaussian id), ...] the alpha test nearest 1/255 at every pixel explained by one (oracle.forced_alpha_flips takes them)}."""
+    "decisions": [(x, y, gaussian id), ...] the alpha test nearest 1/255 at every pixel explained by one, "T_pixels": [(x, y), ...] the pixels explained by their
+    transmittance (oracle.forced_alpha_flips takes both)}."""
     gx = (W + 15) // 16
     ys, xs = np.nonzero(moved)
     out = {"pixels": int(ys.size), "explained": 0, "by": {"alpha_threshold": 0, "subtile_cull": 0, "T_threshold": 0}, "unexplained": [], "gaussians": set(),
-           "decisions": []}  # decisions: (x, y, gaussian id) of the per-pixel alpha test nearest its threshold at every pixel explained that way
+           "decisions": [], "T_pixels": []}  # decisions: (x, y, gaussian id) of the per-pixel alpha test nearest its threshold at every pixel explained that way
     cull_cache = {}
     for y, x in list(zip(ys.tolist(), xs.tolist()))[:limit]:
         ids = _entries(ranges, point_list, gx, x, y)
@@ -114,6 +115,7 @@ def explain_moved_pixels(moved, *, W, H, ranges, point_list, conic_opacity, mean
                 for ft in (final_T_a, final_T_b):
                     if ft is not None and abs(float(ft[y * W + x]) / 1e-4 - 1.0) <= T_TOL:
                         why = "T_threshold"
+                        out["T_pixels"].append((int(x), int(y)))
                         out["gaussians"].update(ids[a >= _THR * (1.0 - ALPHA_TOL)].tolist())
                         break
         if why is None:

@@ -238,18 +238,24 @@ def blend_nudge(alpha: float = 0.0, T: float = 0.0, cull_alpha: float = 0.0):
 
 
 @contextlib.contextmanager
-def forced_alpha_flips(decisions, W: int):
+def forced_alpha_flips(decisions, W: int, T_pixels=()):
     """Inside the block the oracle takes the per-pixel alpha test of every (x, y, gaussian_id) in `decisions` the OTHER way (blends what it would skip,
-    skips what it would blend) and nothing else differently: the exact form of blend_nudge for one decision that sits on its threshold."""
+    skips what it would blend), and at every (x, y) of `T_pixels` the "test_T < 1e-4: stop" decision of the step whose test_T lies within 2e-6 (relative) of
+    1e-4 -- and nothing else differently: the exact form of blend_nudge for single decisions that sit on their threshold."""
     L = lib()
     L.orc_set_forced_alpha_flips.argtypes = [ctypes.c_int, ctypes.c_void_p]
     L.orc_set_forced_alpha_flips.restype = None
+    L.orc_set_forced_T_flips.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    L.orc_set_forced_T_flips.restype = None
     keys = np.ascontiguousarray([((int(y) * int(W) + int(x)) << 32) | (int(g) & 0xFFFFFFFF) for x, y, g in decisions], dtype=np.uint64)
+    pix = np.ascontiguousarray([int(y) * int(W) + int(x) for x, y in T_pixels], dtype=np.uint32)
     L.orc_set_forced_alpha_flips(int(keys.size), keys.ctypes.data_as(ctypes.c_void_p))
+    L.orc_set_forced_T_flips(int(pix.size), pix.ctypes.data_as(ctypes.c_void_p))
     try:
         yield
     finally:
         L.orc_set_forced_alpha_flips(0, None)
+        L.orc_set_forced_T_flips(0, None)
 
 
 def num_threads() -> int:

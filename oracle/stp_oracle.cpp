@@ -46,6 +46,15 @@ static float g_blend_alpha_thr = ALPHA_THRESHOLD, g_blend_T_thr = T_THRESHOLD, g
 // ... and single decisions taken the other way: (pixel index << 32 | Gaussian id) of per-pixel alpha tests whose outcome is inverted (orc_set_forced_alpha_flips,
 // sorted) -- a whole frame has dozens of alphas within any band around 1/255, moving the threshold for all of them is too blunt there
 static std::vector<uint64_t> g_forced_alpha;
+static std::vector<uint32_t> g_forced_T; // pixel indices (sorted) whose "test_T < 1e-4: stop" decision is inverted at the step where test_T sits within 2e-6 (relative) of the threshold
+static inline bool T_stops(float test_T, int W, int px, int py)
+{
+    bool stop = test_T < g_blend_T_thr;
+    if (!g_forced_T.empty() && std::fabs(test_T / T_THRESHOLD - 1.0f) <= 2e-6f &&
+        std::binary_search(g_forced_T.begin(), g_forced_T.end(), (uint32_t)((size_t)py * (size_t)W + (size_t)px)))
+        stop = !stop;
+    return stop;
+}
 static inline bool alpha_skips(float alpha, int W, int px, int py, int id)
 {
     bool skip = alpha < g_blend_alpha_thr;
@@ -603,7 +612,7 @@ inline bool blend_backward(const RenderCtx& c, GradAcc& g, BwdPixel& b, int px, 
     const float* co = &f.conic_opacity[4 * (size_t)id];
     const float alpha = std::min(0.99f, co[3] * G);
     const float test_T = b.T * (1.0f - alpha);
-    if (test_T < g_blend_T_thr) return false;
+    if (T_stops(test_T, f.W, px, py)) return false;
     const float dx = f.means2D[2 * (size_t)id] - (float)px;
     const float dy = f.means2D[2 * (size_t)id + 1] - (float)py;
     const float dchannel_dcolor = alpha * b.T;
@@ -684,7 +693,7 @@ void render_global_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                     float G, alpha;
                     if (!eval_alpha(f, id, px, py, G, alpha)) continue;
                     const float test_T = T * (1 - alpha);
-                    if (test_T < g_blend_T_thr) break;
+                    if (T_stops(test_T, f.W, px, py)) break;
                     for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)id + ch] * alpha * T;
                     if (c.debug_depth) { // ref: forward.cu:337-341: distance camera - mean, whatever the sort order
                         const V3 d = {c.cam.x - c.means3D[3 * (size_t)id], c.cam.y - c.means3D[3 * (size_t)id + 1], c.cam.z - c.means3D[3 * (size_t)id + 2]};
@@ -829,7 +838,7 @@ void render_kbuffer(OrcFrame& f, const RenderCtx& c, float* out, GradAcc* g, con
                     if (!BACKWARD) {
                         const float a = win.store[0];
                         const float test_T = T * (1 - a);
-                        if (test_T < g_blend_T_thr) { win.num--; done = true; return; }
+                        if (T_stops(test_T, f.W, px, py)) { win.num--; done = true; return; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)win.id[0] + ch] * a * T;
                         if (c.debug_depth) depth_acc += win.depth[0] * a * T; // ref: resorted_render.cuh:107
                         T = test_T;
@@ -947,7 +956,7 @@ struct HierSubTile {
         bool ok;
         if (!BACKWARD) {
             const float test_T = p.T * (1.0f - st);
-            if (test_T < g_blend_T_thr) ok = false;
+            if (T_stops(test_T, c->f->W, p.px, p.py)) ok = false;
             else {
                 for (int ch = 0; ch < 3; ch++) p.C[ch] += c->feat[3 * (size_t)id + ch] * st * p.T;
                 if (c->debug_depth) p.depth_acc += p.head.depth[0] * st * p.T; // ref: :1005-1008
@@ -1170,7 +1179,7 @@ void render_full_fwd(OrcFrame& f, const RenderCtx& c, float* out)
                         const float alpha = std::min(0.99f, co[3] * expf(-power));
                         if (alpha_skips(alpha, f.W, px, py, id)) continue;
                         const float test_T = T * (1 - alpha);
-                        if (test_T < g_blend_T_thr) { done = true; break; }
+                        if (T_stops(test_T, f.W, px, py)) { done = true; break; }
                         for (int ch = 0; ch < 3; ch++) C[ch] += c.feat[3 * (size_t)id + ch] * alpha * T;
                         if (c.debug_depth) depth_acc += win[i].key * alpha * T; // ref: resorted_render.cuh:647
                         T = test_T;
@@ -1604,6 +1613,12 @@ void orc_set_forced_alpha_flips(int n, const uint64_t* keys) // n = 0: none
 {
     g_forced_alpha.assign(keys, keys + (n > 0 ? n : 0));
     std::sort(g_forced_alpha.begin(), g_forced_alpha.end());
+}
+
+void orc_set_forced_T_flips(int n, const uint32_t* pixels) // n = 0: none
+{
+    g_forced_T.assign(pixels, pixels + (n > 0 ? n : 0));
+    std::sort(g_forced_T.begin(), g_forced_T.end());
 }
 
 int orc_num_threads(void)

@@ -38,8 +38,8 @@ def _matches_a_nudged_oracle(scene, sd, g, backward, img_tol, grad_tol, ex, tile
     import contextlib
     from oracle import oracle as orc
     tries = []
-    if ex and ex.get("decisions"):
-        tries.append(lambda: orc.forced_alpha_flips(ex["decisions"], scene.W))
+    if ex and (ex.get("decisions") or ex.get("T_pixels")):
+        tries.append(lambda: orc.forced_alpha_flips(ex.get("decisions", []), scene.W, T_pixels=ex.get("T_pixels", [])))
     for frac in (0.1, 0.25, 0.5, 1.0):
         for sign in (1.0, -1.0):
             tries.append(lambda v=sign * frac * 6e-7 / 255.0: orc.blend_nudge(alpha=v))

@@ -263,3 +263,15 @@ def test_forced_alpha_flip_changes_one_pixel_and_resets():
     assert set(changed.tolist()) <= set(ids.tolist()) and gid in changed
     again = orc.forward_scene(sc, sd)
     assert np.array_equal(again.color, base.color)
+
+
+def test_forced_T_flip_touches_only_a_step_on_the_threshold():
+    """The transmittance side of oracle.forced_alpha_flips: a pixel named in T_pixels changes only if one of its steps has test_T within 2e-6 (relative) of 1e-4 --
+    naming pixels that are nowhere near saturation changes nothing; the state is restored afterwards."""
+    sc = scenes.make_scene(P=600, W=64, H=48, sigma_min=2.0, sigma_max=8.0, seed=5, camera="orbit")
+    sd = settings_dict(3)
+    base = orc.forward_scene(sc, sd)
+    with orc.forced_alpha_flips([], sc.W, T_pixels=[(x, y) for y in range(0, sc.H, 3) for x in range(0, sc.W, 3)]):
+        f2 = orc.forward_scene(sc, sd)
+    assert np.array_equal(f2.color, base.color)   # (no pixel of this scene ends within 2e-6 of the threshold)
+    assert np.array_equal(orc.forward_scene(sc, sd).color, base.color)
