@@ -33,6 +33,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "stopthepop-rasterization_amd"))
 sys.path.insert(0, ROOT)
 
+# (multi-process GPU work on this pool: the host driver only supports dmabuf IPC -- without this RCCL fails with `hipIpcGetMemHandle: invalid argument`.
+# The boxes export it already; a launcher that builds its own environment may not)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
