@@ -319,9 +319,11 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
                 else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
         elif mode == 2:
             win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
+            # (launch_kbuffer_wave: windows >= 8 run the LDS-ring kernel unless STP_KBUFFER=wave asks for the register window)
+            fwd_kernel = "render_kbuffer_ring_kernel" if (win >= 8 and os.environ.get("STP_KBUFFER", "") != "wave") else "render_kbuffer_wave_kernel"
             kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
                 (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
-                 f"render_kbuffer_wave_kernel<{win}, {2 if recording else 0}, true>")
+                 f"{fwd_kernel}<{win}, {2 if recording else 0}, true>")
         else:
             kname = {0: "render_global", 1: "render_full"}[mode] + ("_bwd_kernel" if dom == "BwdRender" else "_fwd_kernel")
         prof, prof_note = profile_entry(kname, f"{wl.name}-{wl.variant}")
@@ -590,13 +592,13 @@ def reference_parity(wl, dev, timing_steps=10, timing_warmup=3, with_fma=True, t
 OTHER_WORKLOADS = (("C2-min", "C2", "min", False), ("C3", "C3", "full", False), ("C4-1gpu-fwd", "C4", "full", True), ("C5", "C5", "full", False))
 
 
-def other_workloads(dev, steps=10, warmup=3, parity=True):
+def other_workloads(dev, steps=10, warmup=3, parity=True, detail=False, scale=1.0):
     """The BASELINE configurations that are not the headline, `steps` timed steps each on the same code in the same process
     (same harness as the headline: wall clock between two synchronisations, stage hipEvents, SURVEY 8(d) bytes)."""
     out = {}
     for label, name, variant, fwd_only in OTHER_WORKLOADS:
         try:
-            wl = Workload(name, variant, dev, fwd_only=fwd_only)
+            wl = Workload(name, variant, dev, fwd_only=fwd_only, scale=scale)
             dt, stage_ms, stats, _ = timed_region(wl, steps, warmup, 0.2, lambda: torch.cuda.synchronize(dev))
             ms = 1000.0 * dt / steps
             roof, info = describe(wl, stage_ms, ms)
@@ -607,12 +609,14 @@ def other_workloads(dev, steps=10, warmup=3, parity=True):
                           "resolution": f"{wl.scene.W}x{wl.scene.H}", "passes": "fwd" if wl.fwd_only else "fwd+bwd",
                           "dominant_kernel": roof["kernel"], "dominant_ms": roof["avg_launch_ms"],
                           "algorithmic_bytes_per_launch": roof["algorithmic_bytes_per_launch"], "achieved_GBps": roof["achieved"],
-                          "frac": roof["frac"]}
+                          "frac": roof["frac"], "traffic": roof["traffic"], "traffic_source": roof["traffic_source"]}
+            t_leg = time.perf_counter()
             if parity:
                 try:   # whole frame against the reference's own kernels (IEEE build), default library and libstp_raster_fma.so (+ its speed)
-                    out[label].update(reference_parity(wl, dev, timing_steps=steps, timing_warmup=warmup, time_fma=label in ("C3", "C5")))
+                    out[label].update(reference_parity(wl, dev, timing_steps=steps, timing_warmup=warmup, with_fma=detail, time_fma=detail and label in ("C3", "C5")))
                 except Exception as ex:
                     out[label]["vs_reference_error"] = repr(ex)[:300]
+            out[label]["checker_seconds"] = round(time.perf_counter() - t_leg, 1)
             wl.free()
             del wl
         except Exception as ex:  # the headline stands on its own
@@ -622,6 +626,135 @@ def other_workloads(dev, steps=10, warmup=3, parity=True):
         _C.clear_scratch_pool(dev)
         torch.cuda.empty_cache()
     return out
+
+LINE_CAP_BYTES = 8192       # the driver keeps a bounded tail of stdout: round 5's 24.7 KB line could not be parsed
+STR_CAP = 140               # (and shortens long strings)
+
+
+def _short(x, n=STR_CAP):
+    return x if not isinstance(x, str) or len(x) <= n else x[:n - 1] + "~"
+
+
+def _parity_summary(rec):
+    """<= 300 bytes of one parity record (oracle window or whole frame vs the reference build): what a reader needs to see that the
+    frame is the reference algorithm's; the decisions, criteria and records behind it stay in bench_detail.json."""
+    if not isinstance(rec, dict):
+        return None
+    o = {}
+    for k_in, k_out in (("keys_bit_equal", "keys_equal"), ("list_bit_equal", "list_equal"), ("psnr_db", "psnr_db")):
+        if k_in in rec:
+            o[k_out] = rec[k_in]
+    if "max_abs" in rec:
+        o["max_abs"] = float(f"{rec['max_abs']:.3g}")
+    if "pixels_moved_gt_2e-6" in rec:
+        o["moved"] = rec["pixels_moved_gt_2e-6"]
+    if "grad_rel_max" in rec:
+        o["grad_rel_max"] = float(f"{rec['grad_rel_max']:.3g}")
+    res = rec.get("residual")
+    if isinstance(res, dict):
+        if "explained" in res:
+            o["explained"] = res["explained"]
+        closure = res.get("forced_oracle") or res.get("nudged_oracle")
+        if isinstance(closure, dict) and "closes_the_residual" in closure:
+            o["closed"] = closure["closes_the_residual"]
+            if "max_abs" in closure:
+                o["closed_max_abs"] = float(f"{closure['max_abs']:.3g}")
+            if "grad_rel_max" in closure:
+                o["closed_grad_rel_max"] = float(f"{closure['grad_rel_max']:.3g}")
+        if "error" in res:
+            o["residual_error"] = _short(res["error"], 80)
+    return o
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's keys + config + stage_ms + step_ms{median,min,max} + roofline (with `second`) + roofline_valu +
+    cpu_baseline + a short parity summary + one compact object per other workload.  Everything else the run produced (worst / median step
+    records, decisions, criteria, as_configured, side legs) is in bench_detail.json next to this script and on stderr."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    o = {k: out[k] for k in keep if k in out}
+    cfg = dict(out.get("config", {}))
+    cfg["workload"] = _short(cfg.get("workload", ""))
+    cfg.pop("step", None)
+    o["config"] = cfg
+    o["stage_ms"] = out.get("stage_ms")
+    sm = out.get("step_ms") or {}
+    o["step_ms"] = {k: sm[k] for k in ("median", "min", "max") if k in sm}
+    rf = out.get("roofline")
+    if isinstance(rf, dict):
+        r = {k: rf[k] for k in ("bound", "priced_on", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                                "design_bytes_per_launch", "avg_launch_ms", "whole_step_frac") if k in rf}
+        if rf.get("traffic") is None:
+            r["traffic_note"] = _short(rf.get("traffic_source", ""), 100)
+        if "second" in rf:
+            r["second"] = rf["second"]
+        o["roofline"] = r
+    rv = out.get("roofline_valu")
+    if isinstance(rv, dict):
+        o["roofline_valu"] = {k: rv[k] for k in ("kernel", "achieved", "peak", "unit", "frac", "limits_the_kernel") if k in rv}
+    if "cpu_baseline" in out:
+        o["cpu_baseline"] = {k: _short(v) for k, v in out["cpu_baseline"].items()}
+    hm = out.get("hbm_measured")
+    if isinstance(hm, dict):
+        o["hbm_measured"] = {k: hm[k] for k in ("read_GBps", "write_GBps", "copy_GBps") if k in hm}
+    par = out.get("parity")
+    if isinstance(par, dict):
+        p = {"against": "CPU oracle (window) + the reference's sources built by hipify-perl+hipcc (whole frame): by the tier rules 'parity unpinned'",
+             "window": par.get("window"), "oracle": _parity_summary(par)}
+        if "vs_reference_ieee_build" in par:
+            p["reference_build"] = _parity_summary(par["vs_reference_ieee_build"])
+        if "vs_reference_error" in par:
+            p["reference_error"] = _short(par["vs_reference_error"], 100)
+        o["parity"] = p
+    for k in ("rccl_ranks", "tile_shard_exchange"):
+        if k in out:
+            o[k] = _short(out[k])
+    for k in ("frame_shard", "tile_shard"):
+        if isinstance(out.get(k), dict):
+            o[k] = {kk: _short(vv) for kk, vv in out[k].items() if kk != "what"}
+    ow = out.get("other_workloads")
+    if isinstance(ow, dict):
+        c = {}
+        for label, w in ow.items():
+            if "error" in w:
+                c[label] = {"error": _short(w["error"], 100)}
+                continue
+            e = {k: w[k] for k in ("value", "ms_per_step", "dominant_kernel", "dominant_ms", "frac") if k in w}
+            e["traffic"] = w.get("traffic")
+            e["stage_ms"] = w.get("stage_ms")
+            rec = w.get("vs_reference_ieee_build")
+            if isinstance(rec, dict):
+                e.update(_parity_summary(rec))
+            if "vs_reference_error" in w:
+                e["reference_error"] = _short(w["vs_reference_error"], 100)
+            c[label] = e
+        o["other_workloads"] = c
+    if "leg_seconds" in out:
+        o["leg_seconds"] = out["leg_seconds"]
+    o["detail"] = "bench_detail.json (+ stderr): step records, decisions, criteria, side legs"
+    return o
+
+
+def emit(result_fd, out):
+    """Full record -> bench_detail.json + stderr; compact record -> the one stdout line, hard-capped."""
+    full = json.dumps(out)
+    for d in (ROOT, os.environ.get("TMPDIR", "/tmp")):
+        try:
+            with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                f.write(full + "\n")
+            break
+        except OSError:
+            continue
+    print("[bench detail] " + full, file=sys.stderr, flush=True)
+    o = compact_line(out)
+    text = json.dumps(o)
+    # shed the optional objects, cheapest first, rather than lose the line (cannot happen with today's field set: a guard, not a plan)
+    for k in ("leg_seconds", "hbm_measured", "roofline_valu", "other_workloads"):
+        if len(text) < LINE_CAP_BYTES:
+            break
+        o.pop(k, None)
+        text = json.dumps(o)
+    assert len(text) < LINE_CAP_BYTES, f"bench line is {len(text)} bytes: the driver cannot parse more than {LINE_CAP_BYTES}"
+    os.write(result_fd, (text + "\n").encode())
 
 
 def main():
@@ -646,6 +779,9 @@ def main():
                          "handing dL/dimage, resident in HBM, to the rasterizer's backward")
     ap.add_argument("--prewarm-seconds", type=float, default=0.5, help="untimed steps before the W warm-up steps (device clock ramp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detail", action="store_true",
+                    help="also run the side legs of rounds 3-5 (libstp_raster_fma.so parity + speed, the reference's default-contraction build, the "
+                         "reference's kernels timed on this GPU, the step with a torch loss): minutes of checker time, all of it in bench_detail.json")
     ap.add_argument("--no-other-workloads", action="store_true", help="N == 1: leave out the other_workloads object (C2-min, C3, C4 on one GPU, C5; 10 steps each)")
     ap.add_argument("--cpu-rows", type=int, default=0, help="tile rows in the CPU-baseline sample (0 = auto)")
     ap.add_argument("--train-forward-only", action="store_true",
@@ -656,6 +792,7 @@ def main():
                     help="self-test of the N > 1 code path on a box with ONE GPU: every rank uses cuda:0 and the process group is gloo (host-staged "
                          "exchange); the numbers mean nothing")
     args = ap.parse_args()
+    t_start = time.perf_counter()
 
     # stdout carries exactly ONE line, the result of rank 0.  Libraries write there too (RCCL prints a five-line version
     # banner through C stdio, which is flushed at exit, i.e. after our line): file descriptor 1 is pointed at stderr for
@@ -791,7 +928,7 @@ def main():
             if rank == 0:
                 o = dict(fallback)
                 o["tile_shard"] = {"error": f"the tile-row exchange did not complete within {args.probe_timeout:.0f} s: this line is the frame-sharded measurement"}
-                os.write(result_fd, (json.dumps(o) + "\n").encode())
+                emit(result_fd, o)
             os._exit(0)
 
         watchdog = threading.Timer(args.probe_timeout, bail)
@@ -819,7 +956,7 @@ def main():
                 if rank == 0:
                     o = dict(out)
                     o["tile_shard"] = {"error": f"timed out after {args.probe_timeout:.0f} s; the headline is unaffected"}
-                    os.write(result_fd, (json.dumps(o) + "\n").encode())
+                    emit(result_fd, o)
                 os._exit(0)
 
             watchdog = threading.Timer(args.probe_timeout, bail2)
@@ -845,16 +982,21 @@ def main():
             out["tile_shard_exchange"] = ("forward: every peer sends its strip as three channel segments straight into rank 0's frame (grouped RCCL send/recv); "
                                           "backward: all-reduce of 36 B per Gaussian between the two halves; the per-Gaussian stages run replicated "
                                           "(DESIGN.md section 7 gives the Amdahl ceiling per N)")
+        legs = {"headline": round(time.perf_counter() - t_start, 1)}
         if world == 1:
+            t_leg = time.perf_counter()
             out["hbm_measured"] = hbm_ceilings(dev)
+            legs["hbm_measured"] = round(time.perf_counter() - t_leg, 1)
         if world == 1 and not args.no_cpu_baseline:
+            t_leg = time.perf_counter()
             checker = checker_legs(scene, sdict, gy, fwd_only, args.cpu_rows, wl.state, wl.leaves,
                                    raster_factory=lambda e: __import__("diff_gaussian_rasterization").GaussianRasterizer(wl.rs._replace(settings=e)),
-                                   es=es, tensors=wl.tensors(), w_img=wl.w_img, wl=wl, dev=dev)
+                                   es=es, tensors=wl.tensors(), w_img=wl.w_img, wl=wl, dev=dev, detail=args.detail)
             out.update(checker)
-        if world == 1 and not args.no_other_workloads and args.workload == "C2" and args.variant == "full" and args.scale == 1.0 \
+            legs["cpu_baseline_and_parity"] = round(time.perf_counter() - t_leg, 1)
+        if world == 1 and not args.no_other_workloads and args.workload == "C2" and args.variant == "full" \
                 and not args.fwd_only and not args.train_forward_only:
-            if not wl.loss:
+            if not wl.loss and args.detail:
                 # the same workload with the step definition of rounds 1-2 (a torch loss inside the step), for continuity
                 wl.loss = True
                 k3 = max(1, min(args.steps, 20))
@@ -865,8 +1007,12 @@ def main():
             wl.free()
             _C.clear_scratch_pool(dev)
             torch.cuda.empty_cache()
-            out["other_workloads"] = other_workloads(dev)
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+            t_leg = time.perf_counter()
+            out["other_workloads"] = other_workloads(dev, detail=args.detail, scale=args.scale)
+            legs["other_workloads"] = round(time.perf_counter() - t_leg, 1)
+        legs["total"] = round(time.perf_counter() - t_start, 1)
+        out["leg_seconds"] = legs
+        emit(result_fd, out)
     os.close(result_fd)
     if dist is not None:
         # the line is out; a rank whose peers have left through a watchdog (or died) must not sit in this barrier until the
@@ -911,7 +1057,7 @@ def _img_err(a, b):
     return {"psnr_db": _psnr(a, b), "max_abs": float(d.max()), "pixels_moved_gt_2e-6": int((d > 2e-6).any(axis=0).sum()), "pixels": int(d[0].size)}
 
 
-def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory, es, tensors, w_img, wl=None, dev=None):
+def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory, es, tensors, w_img, wl=None, dev=None, detail=False):
     """The checker / baseline leg (rank 0, N = 1): everything here is test infrastructure from oracle/, used as the thing
     compared AGAINST and as reported non-target baselines, never as the thing measured.
       cpu_baseline            the CPU oracle timed on a bounded window of the same frame
@@ -973,13 +1119,13 @@ def checker_legs(scene, sdict, gy, fwd_only, rows, state, leaves, raster_factory
             except Exception as ex:
                 par["residual"]["nudged_oracle"] = {"error": repr(ex)[:200]}
         for variant, key in (("ieee", "vs_reference_ieee_build"), ("fast", "vs_reference_default_build")):
-            if not ref.available(variant):
+            if not ref.available(variant) or (variant == "fast" and not detail):
                 continue
             rfr = ReferenceFrame(scene, sdict, fwd_only, variant=variant)
             par[key] = rfr.compare(prod)
             if variant == "ieee":
                 fma = os.path.join(os.path.dirname(_C.library_path()), FMA_LIB_NAME)
-                if os.path.exists(fma) and os.path.basename(_C.library_path()) != FMA_LIB_NAME:
+                if detail and os.path.exists(fma) and os.path.basename(_C.library_path()) != FMA_LIB_NAME:
                     # the second shipped build (depth keys as fma chains, the default of rounds 1-3): same frame, same harness
                     _C.use_library(fma)
                     try:

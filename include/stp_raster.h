@@ -188,6 +188,11 @@ size_t stp_blend_log_bytes_rows(int width, int height, int tile_y0, int tile_y1)
    library keeps a pointer -> value cache for the buffers of this process and reads the header back (one blocking 16-byte copy) for a pointer it
    does not know -- a clone, a copy, a buffer of another process.  Negative (STP_ERR_INVALID_ARGUMENT) for a buffer without a valid header. */
 int stp_blend_log_depth(const void* image_buffer);
+/* Drops the library's cached layout of a binning / image buffer at this address.  An allocator that recycles scratch buffers calls it when
+   it releases or frees one, so that a later tenant of the address -- a clone or a restored copy of ANOTHER forward's buffer, which no forward
+   of this process carved there -- is resolved from the header it carries instead of the previous tenant's entry.  (A forward that carves the
+   address again overwrites the entry by itself.)  Harmless for unknown pointers. */
+void stp_forget_buffer(const void* buffer);
 /* Bytes of a blend log of `depth` records per pixel (depth <= 0: of the DEEPEST log a forward may carve, 512 records) for the tile rows
    [tile_y0, tile_y1) (0, 0 = the whole frame): what a memory policy should budget for a frame whose depth it does not know yet. */
 size_t stp_blend_log_bytes_depth(int width, int height, int tile_y0, int tile_y1, int depth);

@@ -93,7 +93,10 @@ def explain_moved_pixels(moved, *, W, H, ranges, point_list, conic_opacity, mean
     out = {"pixels": int(ys.size), "explained": 0, "by": {"alpha_threshold": 0, "subtile_cull": 0, "T_threshold": 0}, "unexplained": [], "gaussians": set(),
            "decisions": [], "T_pixels": []}  # decisions: (x, y, gaussian id) of the per-pixel alpha test nearest its threshold at every pixel explained that way
     cull_cache = {}
-    for y, x in list(zip(ys.tolist(), xs.tolist()))[:limit]:
+    pix = list(zip(ys.tolist(), xs.tolist()))
+    # pixels beyond `limit` are not examined: they count as UNEXPLAINED (a gate of the form "every moved pixel is explained" must not pass on a prefix)
+    out["unexplained"].extend((x, y) for y, x in pix[limit:])
+    for y, x in pix[:limit]:
         ids = _entries(ranges, point_list, gx, x, y)
         why = None
         if ids.size:

@@ -62,6 +62,7 @@ struct Api {
     decltype(&stp_mark_visible) mark_visible = nullptr;
     decltype(&stp_last_error) last_error = nullptr;
     decltype(&stp_abi_version) abi_version = nullptr;
+    decltype(&stp_forget_buffer) forget_buffer = nullptr;
 } g_api;
 
 int load_library(const std::string& path)
@@ -75,7 +76,8 @@ int load_library(const std::string& path)
     a.mark_visible = reinterpret_cast<decltype(a.mark_visible)>(dlsym(h, "stp_mark_visible"));
     a.last_error = reinterpret_cast<decltype(a.last_error)>(dlsym(h, "stp_last_error"));
     a.abi_version = reinterpret_cast<decltype(a.abi_version)>(dlsym(h, "stp_abi_version"));
-    if (!a.forward || !a.backward_phases || !a.mark_visible || !a.last_error || !a.abi_version)
+    a.forget_buffer = reinterpret_cast<decltype(a.forget_buffer)>(dlsym(h, "stp_forget_buffer"));
+    if (!a.forget_buffer || !a.forward || !a.backward_phases || !a.mark_visible || !a.last_error || !a.abi_version)
         throw std::runtime_error(path + " does not export the C ABI of include/stp_raster.h");
     if (a.abi_version() != STP_ABI_VERSION) throw std::runtime_error(path + ": ABI version mismatch");
     g_api = a; // (a previously loaded library stays mapped: buffers of its forwards may still be in flight)
@@ -107,6 +109,7 @@ void put_back(const torch::Tensor& buf) // caller holds g_mutex
     for (auto& p : fl)
         if (p.t.data_ptr() == buf.data_ptr()) return;
     note_stream_use(buf);
+    g_api.forget_buffer(buf.data_ptr()); // (its next tenant is described by what a forward carves there, or by the header a copy brings along)
     hipEvent_t& ev = g_events[(uintptr_t)buf.data_ptr()];
     if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
     bool recorded = ev && hipEventRecord(ev, c10::hip::getCurrentHIPStream(buf.get_device()).stream()) == hipSuccess;

@@ -392,23 +392,27 @@ LayoutCache g_layout, g_log_depth;
 void remember_layout(const void* binning, uint32_t count, int64_t R) { std::lock_guard<std::mutex> l(g_layout_mutex); g_layout.put(binning, count, R); }
 void remember_log_depth(const void* image, uint32_t depth, int64_t R) { std::lock_guard<std::mutex> l(g_layout_mutex); g_log_depth.put(image, depth, R); }
 // the header a forward left in the buffer: 0 and *value on success, else a negative STP_ERR_* (message set)
-int read_buffer_header(const uint32_t* dev_header, uint32_t magic, const char* what, uint32_t* value)
+// (the copy is ordered on the CALLER's stream -- a clone made on a non-blocking stream is not visible to the null stream's copy -- and waited for;
+//  introspection calls have no stream: they wait for the device first)
+int read_buffer_header(const uint32_t* dev_header, uint32_t magic, const char* what, uint32_t* value, hipStream_t st, bool have_stream)
 {
     uint32_t h[4] = {0, 0, 0, 0};
-    if (hipMemcpy(h, dev_header, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return fail(STP_ERR_HIP, std::string("could not read the header of the ") + what + " buffer"); }
+    if (!have_stream) (void)hipDeviceSynchronize();
+    if (hipMemcpyAsync(h, dev_header, sizeof(h), hipMemcpyDeviceToHost, have_stream ? st : nullptr) != hipSuccess ||
+        hipStreamSynchronize(have_stream ? st : nullptr) != hipSuccess) { (void)hipGetLastError(); return fail(STP_ERR_HIP, std::string("could not read the header of the ") + what + " buffer"); }
     if (h[0] != magic || h[2] != ~h[1])
         return fail(STP_ERR_INVALID_ARGUMENT, std::string("the ") + what + " buffer does not carry a header of this library: it was not written by stp_forward (or has been overwritten)");
     *value = h[1];
     return 0;
 }
 // entries the binning buffer was carved for: cache, else the buffer's own header
-int layout_of(const char* binning, uint32_t R, uint32_t* cap)
+int layout_of(const char* binning, uint32_t R, uint32_t* cap, hipStream_t st = nullptr, bool have_stream = false)
 {
     {
         std::lock_guard<std::mutex> l(g_layout_mutex);
         if (g_layout.get(binning, (int64_t)R, cap) && *cap >= R) return 0;
     }
-    if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(binning), STP_HEADER_MAGIC_BINNING, "binning", cap)) return rc;
+    if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(binning), STP_HEADER_MAGIC_BINNING, "binning", cap, st, have_stream)) return rc;
     if (*cap < R) return fail(STP_ERR_INVALID_ARGUMENT, "the binning buffer was carved for fewer entries than num_rendered");
     remember_layout(binning, *cap, (int64_t)R);
     return 0;
@@ -419,13 +423,13 @@ constexpr uint32_t RUN_AHEAD_AUTO_MAX = 1u << 18;
 std::atomic<int> g_run_ahead{[] { const char* e = std::getenv("STP_RUN_AHEAD"); return (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2; }()};
 
 // depth the image buffer's blend log was carved with: cache, else the buffer's own header (whose offset does not depend on the depth)
-int log_depth_of(const char* image, int64_t R, uint32_t* depth)
+int log_depth_of(const char* image, int64_t R, uint32_t* depth, hipStream_t st = nullptr, bool have_stream = false)
 {
     {
         std::lock_guard<std::mutex> l(g_layout_mutex);
         if (g_log_depth.get(image, R, depth)) return 0;
     }
-    if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(image), STP_HEADER_MAGIC_IMAGE, "image", depth)) return rc;
+    if (int rc = read_buffer_header(reinterpret_cast<const uint32_t*>(image), STP_HEADER_MAGIC_IMAGE, "image", depth, st, have_stream)) return rc;
     if (*depth != 0u && (int)*depth != blend_log_clamp_depth((int)*depth)) return fail(STP_ERR_INVALID_ARGUMENT, "the image buffer's header holds an impossible blend-log depth");
     remember_log_depth(image, *depth, R);
     return 0;
@@ -560,6 +564,13 @@ void stp_reset_size_guesses(void)
             (void)hipMemset(g_mailboxes[d].log_need, 0, sizeof(uint32_t) * 64);
         }
     (void)hipSetDevice(cur);
+}
+void stp_forget_buffer(const void* buffer)
+{
+    if (!buffer) return;
+    std::lock_guard<std::mutex> l(g_layout_mutex);
+    g_layout.map.erase(buffer);
+    g_log_depth.map.erase(buffer);
 }
 int stp_blend_log_depth(const void* image_buffer)
 {
@@ -948,8 +959,8 @@ int stp_backward_phases(int phases, int P, int D, int M, int R, const float* bac
     GeometryState g = carve_geometry(geom_buffer, (size_t)P, with_inv, nullptr);
     // what the buffers were carved with travels with them (cache of this process, else the buffers' own headers): a buffer that carries none is refused
     uint32_t bin_cap = 0, log_depth = 0;
-    if (R > 0) { if (int rc = layout_of(binning_buffer, (uint32_t)R, &bin_cap)) return rc; } // (a run-ahead forward carved it for its capacity)
-    if (uses_blend_log(*settings)) { if (int rc = log_depth_of(image_buffer, (int64_t)R, &log_depth)) return rc; }
+    if (R > 0) { if (int rc = layout_of(binning_buffer, (uint32_t)R, &bin_cap, (hipStream_t)stream, true)) return rc; } // (a run-ahead forward carved it for its capacity)
+    if (uses_blend_log(*settings)) { if (int rc = log_depth_of(image_buffer, (int64_t)R, &log_depth, (hipStream_t)stream, true)) return rc; }
     BinningState b = carve_binning(binning_buffer, (size_t)bin_cap, nullptr);
     ImageState img = carve_image(image_buffer, width, height, f.ty0, f.ty1, (int)log_depth, nullptr);
     if (!radii) radii = g.internal_radii;

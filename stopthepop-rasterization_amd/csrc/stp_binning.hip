@@ -46,12 +46,17 @@ size_t scan_temp_bytes(size_t P)
 // by the scan kernel, by the pass before -- or with a memset in front changed the passes' durations exactly as far as it delayed them).  What
 // counts is the stage: sort stage -10 .. -25 us on every workload (profiles/r04_tilesort_driver_ab.txt).
 // rocprim::detail is private, unversioned API: this driver is written against rocPRIM 4.2 (ROCm 7.2).  Another version must be looked at before it is
-// trusted -- the build stops here instead of mis-tuning or mis-launching silently; STP_TILE_SORT=rocprim (the library's own host function) is the
-// version-proof path and stays compiled in.
+// trusted: there the driver is NOT compiled (a build warning says so), own_onesweep_driver() answers false and launch_sort() takes the library's own
+// host function -- the version-proof path that STP_TILE_SORT=rocprim selects here -- instead of mis-tuning or mis-launching silently.
 #include <rocprim/rocprim_version.hpp>
-static_assert(ROCPRIM_VERSION_MAJOR == 4 && ROCPRIM_VERSION_MINOR == 2,
-              "stp_binning.hip drives rocprim::detail::onesweep_* of rocPRIM 4.2 directly: check the kernels' signatures and the gfx950 tuning against this rocPRIM version, then extend the assert");
+#if ROCPRIM_VERSION_MAJOR == 4 && ROCPRIM_VERSION_MINOR == 2
+#define STP_OWN_ONESWEEP 1
+#else
+#define STP_OWN_ONESWEEP 0
+#warning "stp_binning.hip: the own onesweep driver is written against rocPRIM 4.2; with this rocPRIM the tile-bit sort uses rocprim::radix_sort_pairs (check rocprim::detail::onesweep_* against this version, then extend the #if)"
+#endif
 namespace {
+#if STP_OWN_ONESWEEP
 namespace rpd = rocprim::detail;
 using OsConfig = rpd::wrapped_radix_sort_onesweep_config<rocprim::default_config, uint64_t, uint32_t>;
 constexpr rpd::radix_sort_onesweep_config_params os_params()
@@ -143,6 +148,11 @@ bool own_onesweep_driver(size_t R)
     static const bool always = env && std::strcmp(env, "own") == 0; // (tests: also below OWN_MIN)
     return !lib && (R >= OWN_MIN || (always && R > 0)) && R < OWN_MAX;
 }
+#else  // another rocPRIM: the library's host function only
+struct OsLayout { size_t total; };
+OsLayout os_layout(char*, size_t) { return OsLayout{0}; }
+bool own_onesweep_driver(size_t) { return false; }
+#endif
 } // namespace
 
 size_t sort_temp_bytes(size_t R)
@@ -159,12 +169,16 @@ void sort_zero_region(const BinningState& b, size_t R, uint32_t tiles, uint32_t*
 {
     *ptr = nullptr; *words = 0;
     if (!own_onesweep_driver(R)) return;
+#if STP_OWN_ONESWEEP
     const OsLayout L = os_layout(b.sort_temp, R);
     const uint32_t bit = higher_msb(tiles);
     const size_t places = (bit + OS.radix_bits_per_place - 1) / OS.radix_bits_per_place; // (what launch_sort will run: two at 1080p, of OS_MAX_PLACES)
     const size_t bytes = L.lookback_offset + ((sizeof(rpd::onesweep_lookback_state) * places * OS_RADIX * (size_t)L.sort_blocks + 255) & ~(size_t)255);
     *ptr = reinterpret_cast<uint32_t*>(b.sort_temp);
     *words = (bytes < L.zero_bytes ? bytes : L.zero_bytes) / sizeof(uint32_t);
+#else
+    (void)b; (void)tiles;
+#endif
 }
 
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st)
@@ -185,6 +199,7 @@ hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool 
         return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.keys_unsorted, b.keys, b.point_list_unsorted, b.point_list, (size_t)R,
                                          tile_bits_only ? 32u : 0u, 32u + bit, st);
     }
+#if STP_OWN_ONESWEEP
     const OsLayout L = os_layout(b.sort_temp, (size_t)R);
     const unsigned begin_bit = 32u, end_bit = 32u + bit;
     const unsigned places = (bit + OS.radix_bits_per_place - 1) / OS.radix_bits_per_place;
@@ -207,6 +222,7 @@ hipError_t launch_sort(const FrameParams& f, const BinningState& b, int R, bool 
         from_input = false;
         to_output = !to_output;
     }
+#endif
     return hipGetLastError();
 }
 

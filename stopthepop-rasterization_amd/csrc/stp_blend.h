@@ -85,9 +85,15 @@ __device__ __forceinline__ void report_log_need(uint32_t* word, int nrec, uint32
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
     if (word != nullptr && (threadIdx.x & 63) == 0) {
         const uint32_t v = (tag << 16) | (uint32_t)min(m, 0xFFFF);
-        const uint32_t old = *reinterpret_cast<volatile uint32_t*>(word);
-        if ((old >> 16) != tag) atomicExch(word, v);   // another kind's (or no) report: ours replaces it
-        else if (v > old) atomicMax(word, v);
+        uint32_t old = *reinterpret_cast<volatile uint32_t*>(word);
+        // another kind's (or no) report: ours replaces it; our own kind's: the maximum.  One compare-and-swap loop decides both, so that of
+        // several waves that meet the frame's zeroed word at once the largest report stays (an exchange let a smaller one land last: an
+        // under-sized log for the next frame, i.e. a tile in the re-sorting fallback).  A wave that cannot raise the word issues no atomic.
+        while ((old >> 16) != tag || v > old) {
+            const uint32_t seen = atomicCAS(word, old, v);
+            if (seen == old) break;
+            old = seen;
+        }
     }
 }
 

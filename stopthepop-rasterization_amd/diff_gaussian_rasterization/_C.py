@@ -94,6 +94,8 @@ def _load():
     L.stp_timing_text.restype = ctypes.c_size_t
     L.stp_binning_layout_count.argtypes = [vp, ci]
     L.stp_binning_layout_count.restype = ci
+    L.stp_forget_buffer.argtypes = [vp]
+    L.stp_forget_buffer.restype = None
     if L.stp_abi_version() != 7:
         raise ImportError("libstp_raster.so ABI version mismatch")
     _lib = L

@@ -929,6 +929,22 @@ def test_scratch_buffers_describe_themselves(sd):
         for a, b in zip(got, ref):
             if a is not None and b is not None and b.numel():
                 assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        # an address whose cached layout belongs to a PREVIOUS tenant with the same num_rendered: the exact-size buffer of the
+        # first forward copied over the run-ahead one.  stp_forget_buffer -- what the binding's pool calls when it releases a buffer -- sends
+        # the lookup to the header the copy brought along
+        _C.reset_size_guesses()
+        _, o1 = _direct_forward(sc, sd)                       # first of its kind again: exact size
+        assert o1[0] == R and int(_C._load().stp_binning_layout_count(o1[4].data_ptr(), R)) == R
+        n1 = int(_C._load().stp_binning_buffer_size(R))
+        binning[:n1].copy_(o1[4][:n1])
+        assert int(_C._load().stp_binning_layout_count(binning.data_ptr(), R)) == R + R // 8 + 1024      # the stale entry
+        _C._load().stp_forget_buffer(binning.data_ptr())
+        assert int(_C._load().stp_binning_layout_count(binning.data_ptr(), R)) == R                      # the header
+        got = _direct_backward(sc, sd, ten, out, geom, binning, img)
+        for a, b in zip(got, ref):
+            if a is not None and b is not None and b.numel():
+                assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        _C.release_scratch(o1[5]); _C.release_scratch(o1[4])
         # no header, no backward
         img3 = img.clone(); img3[:16] = 0
         if sd["sort_settings"]["sort_mode"] in (2, 3):
