@@ -133,6 +133,9 @@ def profile_entry(kernel: str, workload: str):
     return (e, t.get("_taken", "")) if e else (None, f"no PMC profile of {kernel} for {workload}")
 
 
+_SCENE_CACHE = {}
+
+
 class Workload:
     """One BASELINE configuration resident in HBM: tensors, the drop-in rasterizer module, one step() = one pass of the hot path."""
 
@@ -145,7 +148,13 @@ class Workload:
         self.train_forward_only = train_forward_only
         self.loss = loss   # True: the step also holds torch's kernels of a weighted-sum loss (the round-1/2 definition of a step)
         self._C = _C
-        self.scene = scene = scenes.config(name, scale=scale)
+        # (C2's scene serves the headline, the fma / loss side legs and C2-min: generated once per process)
+        key = (name, scale)
+        if key not in _SCENE_CACHE:
+            if name != "C2":
+                _SCENE_CACHE.pop(next((k for k in _SCENE_CACHE if k[0] != "C2"), None), None)
+            _SCENE_CACHE[key] = scenes.config(name, scale=scale)
+        self.scene = scene = _SCENE_CACHE[key]
         self.es = es = settings_for(variant, name)
         self.sdict = es.to_dict()
         fo = self.fwd_only
@@ -315,13 +324,13 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
             # (last template argument: the depth keys' reciprocal without its domain check -- the default queue sizes'
             # forward passes on a frame whose Sigma^-1 is tame, which every synthetic workload is)
             frcp = "true" if (head == 4 and mid == 8) else "false"
-            kname = ("render_replay_kernel" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
+            kname = ("render_replay_kernel<false>" if recording else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, 1, false>") if dom == "BwdRender" \
                 else f"render_hier_kernel<{head}, {mid}, {str(cull).lower()}, {2 if recording else 0}, {frcp}>"
         elif mode == 2:
             win = next(w for w in (1, 2, 4, 8, 12, 16, 20, 24) if head <= w or w == 24)
             # (launch_kbuffer_wave: windows >= 8 run the LDS-ring kernel unless STP_KBUFFER=wave asks for the register window)
             fwd_kernel = "render_kbuffer_ring_kernel" if (win >= 8 and os.environ.get("STP_KBUFFER", "") != "wave") else "render_kbuffer_wave_kernel"
-            kname = "render_replay_kernel" if (dom == "BwdRender" and recording) else \
+            kname = "render_replay_kernel<true>" if (dom == "BwdRender" and recording) else \
                 (f"render_kbuffer_kernel<{win}, 1>" if dom == "BwdRender" else
                  f"{fwd_kernel}<{win}, {2 if recording else 0}, true>")
         else:
@@ -329,7 +338,7 @@ def describe(wl, stage_ms, ms_per_step, recording_allowed=True):
         prof, prof_note = profile_entry(kname, f"{wl.name}-{wl.variant}")
         # What bounds the kernel (PMC passes under profiles/): the re-sorting forwards issue VALU instructions 93-96 % of the time; the replay waits for the LDS atomic unit
         # (sums on shared addresses: VALU 68 %, LDS 51 % busy, and neither more waves nor spreading the adds out helps -- profiles/EXPERIMENTS.md, round 5)
-        bound = "hbm" if mode not in (2, 3) else ("lds" if kname == "render_replay_kernel" else "valu")
+        bound = "hbm" if mode not in (2, 3) else ("lds" if kname.startswith("render_replay_kernel") else "valu")
         note = {"hbm": "streaming kernel: achieved / peak / frac are SURVEY 8(d) bytes per launch over the launch duration against 8 TB/s",
                 "valu": "what bounds this kernel is VALU issue (see \"roofline_valu\" / \"valu\"): achieved / peak / frac here are its HBM figures -- SURVEY 8(d) "
                         "bytes per launch over the launch duration against 8 TB/s -- which the contract asks for",

@@ -122,15 +122,59 @@ void put_back(const torch::Tensor& buf) // caller holds g_mutex
 // The reference's resizeFunctional (rasterize_points.cu:33-41): grows a byte tensor on request.  The library may call the
 // binning one twice per forward (a size guess before the num_rendered hand-over, the exact size afterwards if the guess
 // was short: include/stp_raster.h): a request the current buffer already covers returns the same pointer.
+// Which allocation a scratch buffer IS: the library caches (address, num_rendered) -> layout for the buffers its forwards carved, and
+// an address alone does not say whose memory it is now -- a buffer is freed, a clone of ANOTHER forward's buffer lands on its address with the same
+// num_rendered (static views repeat it exactly), and the stale entry would describe it.  The binding knows more than the address: it remembers the
+// StorageImpl of every binning / image buffer its forwards returned (weak reference); a backward that is handed a tensor with another storage at a
+// known address, or one whose storage has died since, tells the library to forget the address first, and the library reads the header the
+// buffer carries (include/stp_raster.h: stp_forget_buffer).
+std::unordered_map<uintptr_t, c10::weak_intrusive_ptr<c10::StorageImpl>> g_storage_of; // behind g_mutex
+void remember_storage(const torch::Tensor& t)
+{
+    if (!t.defined() || t.numel() == 0) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (g_storage_of.size() > 4096) // forwards whose buffers nobody came back for
+        for (auto it = g_storage_of.begin(); it != g_storage_of.end();) it = it->second.expired() ? g_storage_of.erase(it) : std::next(it);
+    g_storage_of.insert_or_assign((uintptr_t)t.data_ptr(), t.storage().getWeakStorageImpl());
+}
+void forget_unless_same_storage(const torch::Tensor& t)
+{
+    if (!t.defined() || t.numel() == 0) return;
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const auto it = g_storage_of.find((uintptr_t)t.data_ptr());
+    if (it != g_storage_of.end() && !it->second.expired() && it->second._unsafe_get_target() == t.storage().unsafeGetStorageImpl()) return;
+    if (it != g_storage_of.end()) g_storage_of.erase(it);
+    g_api.forget_buffer(t.data_ptr());
+}
+
+// Placement experiment (profiles/EXPERIMENTS.md, round 6: the k-buffer ring kernel's speed follows WHERE the frame's scratch buffers lie):
+// STP_SCRATCH_OFFSET_GEOM / _BINNING / _IMAGE = bytes (multiple of 256, below 64 MiB) the buffer of that kind starts behind the start of its
+// allocation.  Read at every request; unset or 0 = the allocation's own start.
+constexpr int64_t OFFSET_SLACK = 64ll << 20;
+int64_t scratch_offset(int kind)
+{
+    static const char* const names[3] = {"STP_SCRATCH_OFFSET_GEOM", "STP_SCRATCH_OFFSET_BINNING", "STP_SCRATCH_OFFSET_IMAGE"};
+    const char* e = kind >= 0 && kind < 3 ? std::getenv(names[kind]) : nullptr;
+    if (!e) return 0;
+    const int64_t v = std::strtoll(e, nullptr, 0) & ~255ll;
+    return v < 0 ? 0 : (v >= OFFSET_SLACK ? OFFSET_SLACK - 256 : v);
+}
+torch::Tensor empty_at_offset(int64_t n, const torch::TensorOptions& opt, int64_t off)
+{
+    return off ? torch::empty({n + OFFSET_SLACK}, opt).narrow(0, off, n) : torch::empty({n}, opt);
+}
+
 struct Resizer {
     torch::Tensor t;
     bool pooled = false, from_pool = false;
+    int kind = -1;
     static void* call(void* user, size_t nbytes_)
     {
         auto* self = static_cast<Resizer*>(user);
         try {
             const int64_t nbytes = (int64_t)nbytes_;
             if (nbytes > 0 && nbytes <= self->t.numel()) return self->t.data_ptr();
+            const int64_t off = scratch_offset(self->kind);
             if (self->pooled && nbytes >= BIG_BYTES) {
                 std::lock_guard<std::mutex> lock(g_mutex);
                 if (self->from_pool) put_back(self->t); // the guess was too small: the buffer goes back, a larger one comes
@@ -139,7 +183,7 @@ struct Resizer {
                 int hit = -1;
                 for (int i = 0; i < (int)fl.size(); i++) {
                     const int64_t n = fl[i].t.numel();
-                    if (n >= nbytes && n <= cap + cap / 4 && (hit < 0 || n < fl[hit].t.numel())) hit = i;
+                    if (n >= nbytes && n <= cap + cap / 4 && fl[i].t.storage_offset() == off && (hit < 0 || n < fl[hit].t.numel())) hit = i;
                 }
                 if (hit >= 0) {
                     Pooled p = fl[hit];
@@ -148,12 +192,13 @@ struct Resizer {
                         (void)hipStreamWaitEvent(c10::hip::getCurrentHIPStream(p.t.get_device()).stream(), p.ev, 0);
                     self->t = p.t;
                     note_stream_use(self->t);
-                } else self->t = torch::empty({cap}, self->t.options());
+                } else self->t = empty_at_offset(cap, self->t.options(), off);
                 self->from_pool = true;
                 g_generation[(uintptr_t)self->t.data_ptr()]++;
                 return self->t.data_ptr();
             }
-            self->t.resize_({nbytes});
+            if (off && nbytes) self->t = empty_at_offset(nbytes, self->t.options(), off);
+            else self->t.resize_({nbytes});
             return nbytes ? self->t.data_ptr() : nullptr;
         } catch (...) { // surfaces as STP_ERR_ALLOC on the C side
             return nullptr;
@@ -222,7 +267,7 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
     const bool zero = P == 0 || windowed;
     torch::Tensor out_color = zero ? torch::zeros({3, H, W}, fopt) : torch::empty({3, H, W}, fopt);
     torch::Tensor radii = zero ? torch::zeros({P}, iopt) : torch::empty({P}, iopt);
-    Resizer geom{torch::empty({0}, bopt), false, false}, binning{torch::empty({0}, bopt), true, false}, img{torch::empty({0}, bopt), true, false};
+    Resizer geom{torch::empty({0}, bopt), false, false, 0}, binning{torch::empty({0}, bopt), true, false, 1}, img{torch::empty({0}, bopt), true, false, 2};
     int rendered = 0;
     if (P != 0) {
         const int M = sh.numel() != 0 ? (int)sh.size(1) : 0;
@@ -246,6 +291,8 @@ rasterize_gaussians(const torch::Tensor& background, const torch::Tensor& means3
         }
         if (rc < 0) raise_last(rc);
         rendered = rc;
+        remember_storage(binning.t);
+        remember_storage(img.t);
     }
     return std::make_tuple(rendered, out_color, radii, geom.t, binning.t, img.t);
 }
@@ -317,6 +364,8 @@ rasterize_gaussians_backward(const torch::Tensor& background, const torch::Tenso
         auto optb = [](const torch::Tensor& t) -> char* { return t.defined() && t.numel() != 0 ? reinterpret_cast<char*>(t.data_ptr()) : nullptr; };
         const c10::hip::HIPGuard guard(dev.index());
         hipStream_t stream = c10::hip::getCurrentHIPStream(dev.index()).stream();
+        forget_unless_same_storage(binningBuffer); // (a clone, a copy or a recycled address: the library then reads the buffer's own header)
+        forget_unless_same_storage(imageBuffer);
         const int rc = g_api.backward_phases(keep_records ? (phases | 8) : phases, P, degree, M, R, fptr(bg_), W, H, &s, fptr(m3_), fptr(sh_), fptr(op_), fptr(col_), fptr(sc_),
                                            scale_modifier, fptr(ro_), fptr(c3_), fptr(vm_), fptr(pm_), fptr(inv_), fptr(cam_), tan_fovx, tan_fovy,
                                            fptr(pix_), radii_.numel() ? radii_.data_ptr<int>() : nullptr, optb(geomBuffer), optb(binningBuffer),
@@ -419,6 +468,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("scratch_generation", &scratch_generation);
     m.def("check_scratch", &check_scratch);
     m.def("release_scratch", &release_scratch);
+    m.def("forget_unless_same_storage", &forget_unless_same_storage);
     m.def("clear_scratch_pool", &clear_scratch_pool);
     m.def("set_scratch_pool_limit", &set_scratch_pool_limit);
     m.def("pooled_sizes", &pooled_sizes);

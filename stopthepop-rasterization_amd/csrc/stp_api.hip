@@ -187,7 +187,7 @@ ImageState carve_image(char* base, int W, int H, int ty0, int ty1, int log_depth
     // that is (wrongly) told a log exists -- e.g. after a render_depth forward -- replays nothing and re-sorts every tile
     // instead of reading a log that was never allocated.
     s.tile_flags = c.take<uint32_t>(T, &off); note("tile_flags", off, T);
-    const size_t recs_per_tile = 4 * (size_t)blend_log_rows(log_depth) * 64; // 4 waves x rows x 64 lanes, 2 B each
+    const size_t recs_per_tile = 4 * (size_t)blend_log_rows(log_depth) * 64; // 4 waves x (depth + spare) records x 64 lanes, 2 B each
     s.log_depth = log_depth;
     if (log_depth > 0) { // blend log of the recording forward: [tile][wave][record][lane]
         const size_t recs = T * recs_per_tile;

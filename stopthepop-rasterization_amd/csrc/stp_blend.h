@@ -53,7 +53,11 @@ struct RenderArgs {
 typedef uint16_t log_t;
 constexpr int LOG_MAX_LIST = 65535;
 #ifndef STP_LOG_PACK
-#define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured, see profiles/EXPERIMENTS.md)
+#define STP_LOG_PACK 0 // 1: two records per 32-bit store, layout [tile][wave][record / 2][lane] of u32 (measured in round 2, see profiles/EXPERIMENTS.md;
+                       // written for the [record][lane] layout of rounds 1-5 and not carried over to the blocked layout)
+#endif
+#if STP_LOG_PACK
+#error "STP_LOG_PACK addressed the [record][lane] log of rounds 1-5; the blocked layout (LOG_BLOCK) keeps a lane's records side by side already"
 #endif
 // Depth of the log = records per pixel it can hold (2 B each; + one spare row, STP_LOG_UNCOND): a RUN-TIME value since round 4
 // (RenderArgs::log_depth), chosen per frame by the host from the blends per pixel the previous recording forwards of the same kind
@@ -69,11 +73,45 @@ constexpr int BLEND_LOG_DEPTH = STP_LOG_DEPTH, BLEND_LOG_DEPTH_MIN = 32, BLEND_L
                          // not blend writes into the slot of the lane's next record, which the next blend overwrites -- and only the
                          // cursor's advance is conditional.  Needs one spare row per wave for the stores behind the last record.
 #endif
-constexpr int BLEND_LOG_SPARE = STP_LOG_UNCOND ? 1 : 0; // rows of 64 records in one wave's slice = depth + BLEND_LOG_SPARE
-__host__ __device__ __forceinline__ size_t log_wave_bytes(int depth) { return (size_t)(depth + BLEND_LOG_SPARE) * 64 * sizeof(log_t); }
-__device__ __forceinline__ char* log_wave_slice(uint32_t* blend_log, int tile, int wave, int depth) // [tile][wave][record][lane]
+// Layout of one wave's slice.  TWO layouts since round 6, by sort mode (log_blocked()):
+//   rows    [record][lane]                 hierarchical mode (rounds 1-5: every mode).  Its lanes blend nearly in step: a store instruction
+//                                          of the wave fills (most of) ONE 128-byte row.
+//   blocked [record / 4][lane][record % 4] k-buffer mode.  A lane's four consecutive records lie side by side in ONE 8-byte piece of a
+//                                          512-byte block; a 128-byte line belongs to sixteen neighbouring lanes = one 4x4 sub-tile.  The k-buffer kernel's lanes do NOT
+//                                          blend in step (a pixel pops when ITS window is full): with rows every store instruction touched as
+//                                          many lines as its lanes' record counts were apart (thirty and more at C3), a line stayed open until
+//                                          the SLOWEST of 64 lanes had passed it, and the L2 wrote partial lines back again and again --
+//                                          0.67 ms of the C3 forward's 2.45 (the same stores aimed at one row: 1.78 ms), and the reason why
+//                                          that kernel's speed followed the physical placement of the image buffer (profiles/EXPERIMENTS.md,
+//                                          round 6).  Blocked: a line is filled by one sub-tile's 16 pixels x 4 consecutive records, open for a
+//                                          few steps whatever the other 48 lanes do: C3 forward 2.28-2.36 (rows, conditional stores) -> 2.14 ms.
+// MEASURED the other way round too (one box, alternating, profiles/r06_experiments/log_layout_ab.txt): blocked in the hierarchical kernel costs
+// three more address instructions per head step and eight lines per store instead of one -- C2-full forward 0.861 -> 0.884 ms, C5 unchanged,
+// replay +1 % everywhere: rows stay there.  The replay reads record k of lane l through the same function (template argument by mode).
+// A slice holds depth records per lane (a multiple of 8) + 8 spare rows (the hierarchical kernel's unconditional stores behind the last
+// record land in the first of them).
+#ifndef STP_LOG_BLOCK
+#define STP_LOG_BLOCK 4 // MEASURED (one box, alternating, C3 forward / replay ms): 2: 2.237 / 1.554, 4: 2.135 / 1.544, 8: 2.162 / 1.561, 16: 2.39 / 1.66, 32: 3.08 / 1.86
+#endif
+constexpr int LOG_BLOCK = STP_LOG_BLOCK;                       // blocked layout: records of one lane side by side
+static_assert(LOG_BLOCK == 2 || LOG_BLOCK == 4 || LOG_BLOCK == 8 || LOG_BLOCK == 16 || LOG_BLOCK == 32, "blocks of 2 .. 32 two-byte records");
+constexpr int LOG_PIECE_SHIFT = LOG_BLOCK == 2 ? 2 : LOG_BLOCK == 4 ? 3 : LOG_BLOCK == 8 ? 4 : LOG_BLOCK == 16 ? 5 : 6; // a lane's piece of a block starts at lane << LOG_PIECE_SHIFT
+constexpr int BLEND_LOG_SPARE = LOG_BLOCK < 8 ? 8 : LOG_BLOCK;                     // record rows (64 records = 128 B) of one wave's slice = depth + BLEND_LOG_SPARE
+__host__ __device__ __forceinline__ size_t log_wave_bytes(int depth) { return (size_t)(depth + BLEND_LOG_SPARE) * 64 * sizeof(uint16_t); }
+__device__ __forceinline__ char* log_wave_slice(uint32_t* blend_log, int tile, int wave, int depth)
 {
     return reinterpret_cast<char*>(blend_log) + (size_t)(tile * 4 + wave) * log_wave_bytes(depth);
+}
+inline bool log_blocked(const StpSettings& s) { return s.sort_mode == 2; } // (MODE_KBUFFER, stp_internal.h)
+#ifndef STP_LOG_LAYOUT
+#define STP_LOG_LAYOUT 0 // A/B builds: 1 = rows everywhere (rounds 1-5), 2 = blocked everywhere
+#endif
+// byte offset, inside the wave's slice, of record k of the lane whose blocked piece starts at lane16 = 16 * lane; j2 = 2 * k (what the
+// recording forwards keep as their cursor).  Blocked: ((j2 << 6) & ~(block bytes - 1)) | piece | (j2 & (piece bytes - 2)) -- v_lshlrev, v_and_or, v_and_or.
+template <bool BLOCKED> __device__ __forceinline__ uint32_t log_record_offset(uint32_t j2, uint32_t lane16) // lane16 = lane << LOG_PIECE_SHIFT
+{
+    if constexpr ((BLOCKED && STP_LOG_LAYOUT != 1) || STP_LOG_LAYOUT == 2) return (((j2 << 6) & ~(128u * LOG_BLOCK - 1u)) | lane16) | (j2 & (2u * LOG_BLOCK - 2u));
+    else return (j2 << 6) | (lane16 >> (LOG_PIECE_SHIFT - 1));
 }
 // what a recording forward reports back: the largest number of blends of any of its pixels (one compare per wave, an atomic only while
 // the maximum still rises), collected per device and kind and handed to the host with the next forward's num_rendered

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/stp_raster.h"
@@ -46,9 +47,17 @@ struct Carver {
     char* base;
     size_t off = 0;
     explicit Carver(char* b) : base(b) {}
+    // STP_CARVE_SKEW=n (experiment, profiles/EXPERIMENTS.md round 6: HBM channel aliasing between the SoA arrays a kernel streams side by side):
+    // n extra bytes (a multiple of ALIGN) in front of every sub-array but the first
+    static size_t skew()
+    {
+        static const size_t v = [] { const char* e = std::getenv("STP_CARVE_SKEW"); return e ? ((size_t)std::strtoull(e, nullptr, 0) & ~(ALIGN - 1)) : (size_t)0; }();
+        return v;
+    }
     template <typename T> T* take(size_t count, size_t* off_out = nullptr)
     {
         off = (off + ALIGN - 1) & ~(ALIGN - 1);
+        if (off) off += skew();
         if (off_out) *off_out = off;
         T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
         off += count * sizeof(T);

@@ -127,33 +127,17 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
 
     // blend log (recording forward): as in stp_render_hier.inc
     char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr;
-    constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
-    const uint32_t log_cap = (uint32_t)a.log_depth * LOG_ROW;
-#if STP_LOG_PACK
-    // packed log: a lane holds the first record of a pair and stores both as one dword -- every store of a wave that is in
-    // step is a full 256-byte row
-    uint32_t log_off = (uint32_t)lane * 4u; // byte offset of my dword in the current pair row (+ 256 per completed pair)
-    int log_held = -1;                      // first record of the current pair, -1: none
+    // (layout [record / 8][lane][record % 8], stp_blend.h; conditional stores: the lanes of this kernel blend in few of its steps, and a store
+    // that re-dirties the line of a lane's NEXT record in every step costs more than the branch saves -- C3 forward 2.45 -> 2.36 ms, round 6)
+    const uint32_t log_cap2 = 2u * (uint32_t)a.log_depth;
+    const uint32_t log_lane16 = (uint32_t)lane << LOG_PIECE_SHIFT;
+    uint32_t log_j2 = 0u;
     auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
-        const bool second = log_held >= 0;
-        if (upd && second && log_off < (uint32_t)(a.log_depth / 2) * 256u)
-            *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held | ((uint32_t)pay << 16);
-        log_off += (upd && second) ? 256u : 0u;
-        log_held = upd ? (second ? -1 : pay) : log_held;
+        if (upd && log_j2 < log_cap2) *reinterpret_cast<log_t*>(log_wave + log_record_offset<true>(log_j2, log_lane16)) = (log_t)pay;
+        log_j2 += upd ? 2u : 0u;
     };
-    auto log_records = [&]() __attribute__((always_inline)) -> int { return 2 * (int)(log_off >> 8) + (int)(log_held >= 0); };
-    auto log_finish = [&]() __attribute__((always_inline)) { // the odd last record
-        if (log_held >= 0 && log_off < (uint32_t)(a.log_depth / 2) * 256u) *reinterpret_cast<uint32_t*>(log_wave + log_off) = (uint32_t)log_held;
-    };
-#else
-    uint32_t log_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
-    auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
-        if (upd && log_off < log_cap) *reinterpret_cast<log_t*>(log_wave + log_off) = (log_t)pay;
-        log_off += upd ? LOG_ROW : 0u;
-    };
-    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_off / LOG_ROW); };
+    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_j2 >> 1); };
     auto log_finish = [&]() __attribute__((always_inline)) {};
-#endif
 
     Window<WIN> head;
     head.init_padded();
@@ -419,19 +403,21 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     // blend log (recording forward): as in stp_render_hier.inc -- the record goes to the lane's current slot in every step (a later blend overwrites
     // it; behind the log's depth everything lands in the spare row), only the cursor's advance is conditional
     char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr;
-    constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
-    const uint32_t log_cap = (uint32_t)a.log_depth * LOG_ROW;
-    uint32_t log_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
-    const uint32_t log_spare = log_cap + (uint32_t)lane * (uint32_t)sizeof(log_t);
+    const uint32_t log_cap2 = 2u * (uint32_t)a.log_depth;
+    const uint32_t log_lane16 = (uint32_t)lane << LOG_PIECE_SHIFT;
+    uint32_t log_j2 = 0u;
     auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
-#if STP_LOG_UNCOND
-        *reinterpret_cast<log_t*>(log_wave + min(log_off, log_spare)) = (log_t)pay;
+#if defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 1   // timing experiment (log WRONG): every store of the wave into its first block -- same instructions, eight lines
+        *reinterpret_cast<log_t*>(log_wave + log_lane16) = (log_t)pay;
+#elif defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 2 // ... no store at all
+#elif defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 4 // ... the unconditional store of rounds 4-5 (into the slot of the lane's next record, or the spare block)
+        *reinterpret_cast<log_t*>(log_wave + log_record_offset<true>(min(log_j2, log_cap2), log_lane16)) = (log_t)pay;
 #else
-        if (upd && log_off < log_cap) *reinterpret_cast<log_t*>(log_wave + log_off) = (log_t)pay;
+        if (upd && log_j2 < log_cap2) *reinterpret_cast<log_t*>(log_wave + log_record_offset<true>(log_j2, log_lane16)) = (log_t)pay;
 #endif
-        log_off += upd ? LOG_ROW : 0u;
+        log_j2 += upd ? 2u : 0u;
     };
-    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_off / LOG_ROW); };
+    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_j2 >> 1); };
 
     // the ring: logical entry k of my window lives in slot (rh + k) mod WIN of my column
     const uint32_t col = (uint32_t)threadIdx.x * 8u;

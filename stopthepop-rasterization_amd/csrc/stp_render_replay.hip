@@ -11,8 +11,9 @@
 // 65535) are flagged by the forward and left to the re-sorting backward kernels, which then run only on those tiles.
 //
 // Layout: one 256-thread workgroup per tile, thread -> pixel mapping identical to the forward (wave = row of four
-// 4x4 sub-tiles), log laid out [tile][wave][k][lane] (the 64 lanes of a wave read record k with one 128-byte load
-// as long as they walk in step).  The nine gradient terms of a blend are summed on chip as 64-bit fixed point (see
+// 4x4 sub-tiles), log laid out as the forward's mode wrote it (stp_blend.h): [tile][wave][k][lane] in hierarchical mode (the 64 lanes of a wave
+// read record k with one 128-byte load as long as they walk in step), [tile][wave][k / 4][lane][k % 4] in k-buffer mode (a wave's load of "record
+// k of every lane" touches the four lines of one 512-byte block, which the next three steps find in the L1).  The nine gradient terms of a blend are summed on chip as 64-bit fixed point (see
 // stp_render_hier.inc for why not fp32 LDS atomics) in ONE set of sums per LIST POSITION, shared by the workgroup:
 // acc[term][position - window start], 512 positions = 36 KB.  A tile whose list fits (all of C2-full) is one window:
 // a blend is nine ds_add_u64 and nothing else, the sums leave the chip once at the end (16-lane group = one position,
@@ -112,6 +113,8 @@ __device__ __forceinline__ int replay_remap_tile(int wg, int n_wg)
 
 // (One kernel for both kinds of tile: as two launches the mixed case -- C2-min -- loses more to the half-empty grids
 // than the lean loop gains.)
+// LOG_BLOCKED: the forward's log layout (stp_blend.h: rows in hierarchical mode, blocked in k-buffer mode)
+template <bool LOG_BLOCKED>
 __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(const RenderArgs a)
 {
 #if STP_REPLAY_COLOR32
@@ -182,15 +185,12 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     // `global_load ... v_off, s[base]` without 64-bit address arithmetic (v_lshl_add_u64 issues at half the rate of a
     // 32-bit add on gfx950, tools/valu_rate_bench.hip).
     const char* const log_wave = log_wave_slice(a.blend_log, tile, __builtin_amdgcn_readfirstlane(w), a.log_depth);
+    // (record indices are clamped to the slice: log_last_row = the last record index that has storage -- with STP_LOG_UNCOND the spare block's --,
+    // log_last_rec = the last one that can hold a record; a clamped read is readable garbage that is never used)
     const uint32_t log_last_row = (uint32_t)(a.log_depth + BLEND_LOG_SPARE - 1), log_last_rec = (uint32_t)(a.log_depth - 1);
-    const uint32_t lane_off = (uint32_t)lane * (uint32_t)sizeof(log_t);
-    constexpr uint32_t LOG_ROW = 64 * sizeof(log_t);
+    const uint32_t lane16 = (uint32_t)lane << LOG_PIECE_SHIFT;
     auto log_at = [&](uint32_t k) __attribute__((always_inline)) -> int { // record k of this lane
-#if STP_LOG_PACK
-        return (int)*reinterpret_cast<const log_t*>(log_wave + (2u * lane_off + (k >> 1) * 256u + (k & 1u) * 2u)); // [record / 2][lane] of u32, low half first
-#else
-        return (int)*reinterpret_cast<const log_t*>(log_wave + (lane_off + k * LOG_ROW));
-#endif
+        return (int)*reinterpret_cast<const log_t*>(log_wave + log_record_offset<LOG_BLOCKED>(2u * k, lane16));
     };
     const float pxf = (float)px, pyf = (float)py;
     const float4* const eC = a.entC + range.x; // list-ordered entry records: mean + Gaussian id, conic + opacity, colour
@@ -624,11 +624,18 @@ extern "C" int stp_debug_replay_stats(unsigned long long* out16)
 
 int blend_log_rows(int depth) { return depth + BLEND_LOG_SPARE; }
 int blend_log_default_depth() { return BLEND_LOG_DEPTH; }
-int blend_log_clamp_depth(int d) { return d < BLEND_LOG_DEPTH_MIN ? BLEND_LOG_DEPTH_MIN : (d > BLEND_LOG_DEPTH_MAX ? BLEND_LOG_DEPTH_MAX : d); }
+int blend_log_clamp_depth(int d) // (a multiple of the block: a lane's records come in pieces)
+{
+    constexpr int Q = LOG_BLOCK < 8 ? 8 : LOG_BLOCK;
+    static_assert(BLEND_LOG_DEPTH_MIN % Q == 0 && BLEND_LOG_DEPTH_MAX % Q == 0 && BLEND_LOG_DEPTH % Q == 0, "log depths are multiples of the block");
+    d = d > BLEND_LOG_DEPTH_MAX ? BLEND_LOG_DEPTH_MAX : (d + Q - 1) / Q * Q;
+    return d < BLEND_LOG_DEPTH_MIN ? BLEND_LOG_DEPTH_MIN : d;
+}
 
 hipError_t launch_hier_replay(const FrameParams& f, const RenderArgs& a, hipStream_t st)
 {
-    hipLaunchKernelGGL(render_replay_kernel, dim3(f.gx * (f.ty1 - f.ty0)), dim3(256), 0, st, a);
+    if (log_blocked(f.s)) hipLaunchKernelGGL(render_replay_kernel<true>, dim3(f.gx * (f.ty1 - f.ty0)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(render_replay_kernel<false>, dim3(f.gx * (f.ty1 - f.ty0)), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

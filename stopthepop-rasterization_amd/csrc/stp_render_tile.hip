@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
     else init_fwd_pixel(fp);
     uint32_t contributor = 0;
     float depth_acc = 0.0f;
-    log_t* const log_base = RECORD ? reinterpret_cast<log_t*>(log_wave_slice(a.blend_log, c.tile, w, a.log_depth)) + lane : nullptr;
+    char* const log_base = RECORD ? log_wave_slice(a.blend_log, c.tile, w, a.log_depth) : nullptr; // [record / 8][lane][record % 8], stp_blend.h
     int nrec = 0;
     const float4* const eF = a.entF + c.range.x;
     const float4* const eCl = a.entC + c.range.x;
@@ -329,7 +329,7 @@ __global__ void __launch_bounds__(BLOCK) render_kbuffer_kernel(const RenderArgs 
             if constexpr (DEPTHVIZ) { if (ok) depth_acc += win.depth[0] * alpha0 * T_before; } // reference resorted_render.cuh:107
             if constexpr (RECORD) {
                 if (ok) {
-                    if (nrec < a.log_depth) log_base[(size_t)nrec * 64] = (log_t)pos;
+                    if (nrec < a.log_depth) *reinterpret_cast<log_t*>(log_base + log_record_offset<true>(2u * (uint32_t)nrec, (uint32_t)lane << LOG_PIECE_SHIFT)) = (log_t)pos;
                     nrec++;
                 }
             }

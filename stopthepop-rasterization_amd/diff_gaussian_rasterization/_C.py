@@ -376,6 +376,8 @@ def binning_array(binningBuffer, R, name):
     num_rendered: the library remembers which, stp_binning_layout_count.)"""
     off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
     L = _load()
+    if binningBuffer.is_cuda:
+        _native().forget_unless_same_storage(binningBuffer)   # (a clone / recycled address is described by the header it carries, not by the address)
     lay = int(L.stp_binning_layout_count(ctypes.c_void_p(binningBuffer.data_ptr()), int(R))) if int(R) > 0 else 0
     if lay < 0:
         _raise_last(lay)
@@ -404,6 +406,8 @@ def blend_log_depth(imgBuffer) -> int:
     L = _load()
     L.stp_blend_log_depth.argtypes = [ctypes.c_void_p]
     L.stp_blend_log_depth.restype = ctypes.c_int
+    if imgBuffer.is_cuda:
+        _native().forget_unless_same_storage(imgBuffer)
     d = int(L.stp_blend_log_depth(ctypes.c_void_p(imgBuffer.data_ptr())))
     if d < 0:
         _raise_last(d)

@@ -8,6 +8,7 @@ The five BASELINE.json configurations are available through ``config(name)``.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, Optional
 
@@ -38,6 +39,20 @@ def normal(seed: int, stream: int, n: int) -> np.ndarray:
     u1 = np.maximum(uniform(seed, 2 * stream + 1000, n), 1e-300)
     u2 = uniform(seed, 2 * stream + 1001, n)
     return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * math.pi * u2)
+
+
+def _each(fn, items, n):
+    """fn(item) for every item; large scenes on a thread pool (numpy's element-wise loops release the GIL: the 48 SH streams of a 6M-Gaussian
+    scene take a minute on one core)."""
+    items = list(items)
+    workers = min(len(items), os.cpu_count() or 1, 16)
+    if n < 200_000 or workers < 2:
+        for it in items:
+            fn(it)
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        list(ex.map(fn, items))
 
 
 @dataclass
@@ -150,10 +165,11 @@ def make_scene(P: int, W: int, H: int, sigma_min: float, sigma_max: float, seed:
     if use_sh:
         M = 16
         shs = np.empty((P, M, 3), dtype=np.float64)
-        for k in range(M):
-            for ch in range(3):
-                std = 0.5 if k == 0 else 0.1
-                shs[:, k, ch] = std * normal(seed, 100 + 3 * k + ch, P)
+
+        def fill(kc):   # (streams are pure functions of (seed, stream, index): the order they are evaluated in changes nothing)
+            k, ch = divmod(kc, 3)
+            shs[:, k, ch] = (0.5 if k == 0 else 0.1) * normal(seed, 100 + 3 * k + ch, P)
+        _each(fill, range(3 * M), P)
     else:
         colors = np.stack([uniform(seed, 200 + ch, P) for ch in range(3)], axis=1)
 

@@ -135,10 +135,10 @@ def test_c_abi_size_and_layout_queries_without_gpu():
     assert cnt.value == 12000 and off.value % 256 == 0
     assert L.stp_geometry_layout(1000, ctypes.byref(s), b"nonsense", ctypes.byref(off), ctypes.byref(cnt)) < 0
     assert b"nonsense" in L.stp_last_error()
-    # blend log of a frame nothing is known about: 192 records + one spare row of 2 bytes per pixel of the tile grid (386 B); a tile-row
+    # blend log of a frame nothing is known about: 192 records + one spare block of eight, 2 bytes each, per pixel of the tile grid (400 B); a tile-row
     # window holds its rows' share; the image-side layout of a window starts at the window's first pixel / tile
     grid_px = ((1920 + 15) // 16) * 16 * ((1080 + 15) // 16) * 16
-    assert _C.blend_log_bytes(1920, 1080) == 386 * grid_px
+    assert _C.blend_log_bytes(1920, 1080) == 400 * grid_px
     assert _C.blend_log_bytes(1920, 1080, (0, 17)) * 4 == _C.blend_log_bytes(1920, 1080)
     L.stp_image_layout_rows.argtypes = [ctypes.c_int] * 4 + [ctypes.c_char_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]
     assert L.stp_image_layout_rows(1920, 1080, 17, 34, b"ranges", ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == 2 * 120 * 17

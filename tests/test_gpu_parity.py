@@ -903,7 +903,8 @@ def test_scratch_buffers_describe_themselves(sd):
     """The reference hands (buffer, num_rendered) to its backward as self-contained blobs.  Ours carry what they were carved with -- the binning
     buffer's capacity (a run-ahead forward carves for a guess, not for num_rendered), the blend log's depth (chosen per frame) -- in a header
     of their own: a CLONE of the buffers, which no cache of the library knows, gives the same gradients as the originals; a buffer whose
-    header is gone is refused instead of being carved on a guess."""
+    header is gone is refused instead of being carved on a guess.  (Round 6: the clones of this test DID land on addresses the library's cache
+    still knew from forwards whose buffers had been freed -- the binding now checks which storage a tensor is before the library may trust the address.)"""
     from diff_gaussian_rasterization import _C
     sc = scenes.make_scene(**DENSE)
     sd = {**sd, "_record_blend_log": True, "_backward_mode": "replay"}
@@ -920,6 +921,9 @@ def test_scratch_buffers_describe_themselves(sd):
         assert int(_C._load().stp_binning_layout_count(binning.data_ptr(), R)) == R + R // 8 + 1024
         ref = _direct_backward(sc, sd, ten, out, geom, binning, img)
         geom2, binning2, img2 = geom.clone(), binning.clone(), img.clone()
+        # (the binding tells the library to forget an address whose tensor is not the storage a forward of this process returned there -- a clone
+        # may well land on the address of a buffer that was freed a moment ago and whose cache entry carries the same num_rendered)
+        _C._native().forget_unless_same_storage(binning2)
         assert int(_C._load().stp_binning_layout_count(binning2.data_ptr(), R)) == R + R // 8 + 1024   # read from the clone's own header
         if sd["sort_settings"]["sort_mode"] in (2, 3):
             assert _C.blend_log_depth(img2) == _C.blend_log_depth(img) > 0
