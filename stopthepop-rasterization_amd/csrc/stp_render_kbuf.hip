@@ -122,6 +122,11 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     const float4* const eF = a.entF + range.x;
     const int list_last = max(total - 1, 0);
     auto ent_row = [&](const float4* base, int pos) __attribute__((always_inline)) -> float4 { // SGPR base + 32-bit offset
+#if defined(STP_KB_ENT_NT) && STP_KB_ENT_NT   // experiment: the entry records as non-temporal loads (they stream through; the log's lines should stay in the L2)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4)));
+        return make_float4(v.x, v.y, v.z, v.w);
+#endif
         return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4));
     };
 
@@ -397,6 +402,11 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     const float4* const eF = a.entF + range.x;
     const int list_last = max(total - 1, 0);
     auto ent_row = [&](const float4* base, int pos) __attribute__((always_inline)) -> float4 { // SGPR base + 32-bit offset
+#if defined(STP_KB_ENT_NT) && STP_KB_ENT_NT   // experiment: the entry records as non-temporal loads (they stream through; the log's lines should stay in the L2)
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4)));
+        return make_float4(v.x, v.y, v.z, v.w);
+#endif
         return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4));
     };
 
@@ -597,9 +607,15 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     int* const stA = s_stage + (w * 4 + 2 * half) * 32;
     const int* const st_row = s_stage + (w * 4 + s) * 32;
     const float qxc = (float)(px - (q & 1)) + 0.5f, qyc = (float)(py - (q >> 1)) + 0.5f;
+#ifndef STP_KB_SYNC
+#define STP_KB_SYNC 0 // experiment: the four waves of the tile meet at a workgroup barrier every STP_KB_SYNC entries of the list (every wave the same number
+                      // of times, also one that has left the loop): keeps their reads of the entry records inside one stretch of the list
+#endif
+    int sync_at = 0; // (list position of my next barrier)
 #pragma unroll 1
     for (int base = 0; base < total; base += 32) {
         if (!__any(active)) break;
+        if (STP_KB_SYNC && base >= sync_at) { __builtin_amdgcn_s_barrier(); sync_at += STP_KB_SYNC; }
         const int ep = base + e;
         bool keepA = false, keepB = false;
         if (ep < total) {
@@ -639,6 +655,7 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
             head_rounds(false);
         }
     }
+    if (STP_KB_SYNC) for (; sync_at < total; sync_at += STP_KB_SYNC) __builtin_amdgcn_s_barrier(); // (the barriers I did not reach: my siblings count on them)
     head_rounds(true);
     // drain: what is left in the window, front first.  Only a pop of a FULL window can be the reference's pop "in front of the next entry"
     if (rn != WIN) cfull = total;
