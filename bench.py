@@ -172,7 +172,7 @@ class Workload:
         self.raster = tile_shard.TileRowShardedRasterizer(self.rs, dist, rank, world) if sharded else dgr.GaussianRasterizer(self.rs)
         self.leaves = [self.means3D, self.means2D, self.opac, self.scales, self.rots, self.shs]
         self.state = {}
-        self.label = f"{name}-{variant}" if name in ("C2", "C2L", "C4", "C5", "L1") else name
+        self.label = f"{name}-{variant}" if name in ("C2", "C2L", "C2H", "C4", "C5", "L1") else name
 
     def tensors(self):
         return (self.means3D, self.means2D, self.opac, self.shs, self.scales, self.rots)
@@ -771,7 +771,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "L1", "C2L"])
+    ap.add_argument("--workload", default="C2", choices=["C1", "C2", "C3", "C4", "C5", "L1", "C2L", "C2H"])
     ap.add_argument("--variant", default="full", choices=["full", "min"])
     ap.add_argument("--shard", default=None, choices=["tilerows", "frames"],
                     help="N > 1: what the ranks share.  Default: tilerows (north star: ONE frame partitioned by screen-tile row, strips "

@@ -860,6 +860,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
             STP_DEBUG_SYNC("sort");
             STP_TRY(launch_ranges(f, b, img, L, st), "tile ranges");
             STP_DEBUG_SYNC("ranges");
+            if (tile_order_enabled()) STP_TRY(launch_tile_order(f, img, st), "tile order");
         }
         STP_TRY(colours.join(), "join colour stream"); // (the entry gather -- or, in GLOBAL mode, the render kernel -- reads the colours)
         if (tile_local_sort) STP_TRY(launch_tile_sort_gather(f, g, b, img, L, atomic_bin, st), "tile sort + entry gather");

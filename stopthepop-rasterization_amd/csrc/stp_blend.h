@@ -41,6 +41,7 @@ struct RenderArgs {
     uint32_t* log_need;    // recording forwards: where the frame's largest blend count per pixel is reported (report_log_need), or nullptr
     uint32_t log_tag;      // 16 bits that identify the frame's KIND in that word (the words are shared by the kinds that map to one guess slot)
     uint32_t* tile_flags;
+    const uint32_t* tile_order; // nullptr, or workgroup j of the render kernels takes tile tile_order[j] of the frame's window: longest list first (tile_order_kernel)
     int flag_mode; // resorting backward: 0 = all tiles, 1 = only tiles with tile_flags != 0
     // debug depth visualisation (StpSettings::debug_visualization == STP_DEBUG_DEPTH): the forward kernels write
     // sum(depth * alpha * T) to channel 0 and T to channel 1 of out_color instead of the colour

@@ -183,6 +183,9 @@ struct BackwardParams {
 hipError_t launch_preprocess(const FrameParams& f, const GeometryState& g, int* radii, uint32_t* tile_counts, hipStream_t st); // tile_counts: nullptr = do not count per tile
 hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int tile0, int n_tiles, bool with_log, bool tile_counters, hipStream_t st); // status, ranges, tile flags (+ tile counters) of the window's tiles
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
+// Longest-list-first order of the window's tiles for the render kernels' workgroups (into ImageState::tile_cursor, free outside STP_SORT=counters)
+bool tile_order_enabled();
+hipError_t launch_tile_order(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st);
 hipError_t launch_block_prefix_mailbox(const FrameParams& f, const GeometryState& g, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st); // second level of the scan + the hand-over

@@ -607,6 +607,33 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
     if (idx == L - 1 && valid) ranges[cur].y = (uint32_t)L;
 }
 
+// Workgroups of a launch are dispatched in index order, and a render workgroup's time is its tile's list: with the longest lists LAST (wherever
+// the scene puts them) the launch ends with a few long workgroups on an otherwise idle chip.  One workgroup orders the window's tiles by list
+// length, longest first (counting sort on 256 length classes: 16 entries apiece up to 2048, 128 apiece beyond); the render kernels' workgroup j
+// then takes tile order[j].  The entry records are per tile: nothing the render kernels read is shared between neighbouring tiles, so the XCD-aware
+// contiguous order they use otherwise buys them nothing.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int tile0, int T, const uint2* __restrict__ ranges_, uint32_t* __restrict__ order)
+{
+    __shared__ uint32_t s_hist[256];
+    const uint2* __restrict__ ranges = ranges_ + tile0;
+    const int tid = (int)threadIdx.x;
+    auto klass = [](uint32_t len) { return 255u - (len < 2048u ? (len >> 4) : min(127u, (len - 2048u) >> 7) + 128u); }; // 0 = the longest
+    if (tid < 256) s_hist[tid] = 0u;
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) atomicAdd(&s_hist[klass(ranges[t].y - ranges[t].x)], 1u);
+    __syncthreads();
+    if (tid < 64) { // exclusive scan of the 256 counters by one wave: four per lane
+        uint32_t c[4], sum = 0;
+        for (int k = 0; k < 4; k++) { c[k] = s_hist[4 * tid + k]; sum += c[k]; }
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (tid >= o) inc += v; }
+        uint32_t run = inc - sum;
+        for (int k = 0; k < 4; k++) { s_hist[4 * tid + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_hist[klass(ranges[t].y - ranges[t].x)], 1u)] = (uint32_t)t;
+}
+
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
 {
 #pragma clang fp contract(off)
@@ -755,6 +782,22 @@ hipError_t launch_ranges(const FrameParams& f, const BinningState& b, const Imag
         e = hipGetLastError();
     }
     return e;
+}
+
+bool tile_order_enabled()
+{
+    // MEASURED (round 6, one box, alternating, profiles/r06_experiments/tile_order_ab.txt; forward / replay ms): C2-full 0.855 / 0.855 -> 0.822 / 0.824 (432 -> 443
+    // frames/s: even the homogeneous frame ends on a tail), C2L (40 % of the Gaussians in 12 clusters) 1.03 / 0.98 -> 0.75 / 0.72 (373 -> 465 frames/s), C2H
+    // 0.96 / 0.855 -> 0.61 / 0.51, C3 +1.3 %, C5 unchanged; the order kernel itself 9 us.  STP_TILE_ORDER=0: the XCD-contiguous order of rounds 1-5.
+    static const bool on = [] { const char* e = std::getenv("STP_TILE_ORDER"); return !(e && e[0] == '0'); }();
+    return on;
+}
+hipError_t launch_tile_order(const FrameParams& f, const ImageState& img, hipStream_t st)
+{
+    const int T = f.gx * (f.ty1 - f.ty0);
+    if (T <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, f.gx * f.ty0, T, img.ranges, img.tile_cursor + f.gx * f.ty0);
+    return hipGetLastError();
 }
 
 // Entry data in list order for the per-pixel-sort render kernels (BinningState::entA..entF): one thread per tile-list

@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
     const int rows = a.ty1 - a.ty0;
-    const int t = kb_remap_tile((int)blockIdx.x, a.gx * rows);
+    const int t = a.tile_order ? (int)a.tile_order[blockIdx.x] : kb_remap_tile((int)blockIdx.x, a.gx * rows);
     const int tile_x = t % a.gx, tile_y = a.ty0 + t / a.gx, tile = tile_y * a.gx + tile_x;
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);
@@ -373,7 +373,7 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int s = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
     const int rows = a.ty1 - a.ty0;
-    const int t = kb_remap_tile((int)blockIdx.x, a.gx * rows);
+    const int t = a.tile_order ? (int)a.tile_order[blockIdx.x] : kb_remap_tile((int)blockIdx.x, a.gx * rows);
     const int tile_x = t % a.gx, tile_y = a.ty0 + t / a.gx, tile = tile_y * a.gx + tile_x;
     const uint2 range = a.ranges[tile];
     const int total = (int)(range.y - range.x);

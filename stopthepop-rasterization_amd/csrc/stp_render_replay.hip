@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256, STP_REPLAY_OCC) render_replay_kernel(cons
     const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
     const int s = lane >> 4, x = lane & 15, m = x >> 2, q = x & 3;
     const int rows = a.ty1 - a.ty0;
-    const int t = replay_remap_tile((int)blockIdx.x, a.gx * rows);
+    const int t = a.tile_order ? (int)a.tile_order[blockIdx.x] : replay_remap_tile((int)blockIdx.x, a.gx * rows);
     const int tile_x = t % a.gx, tile_y = a.ty0 + t / a.gx, tile = tile_y * a.gx + tile_x;
     if (a.tile_flags[tile] != 0u) return; // log overflow: the re-sorting backward takes this tile
     const uint2 range = a.ranges[tile];

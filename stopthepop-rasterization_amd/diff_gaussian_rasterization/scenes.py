@@ -212,6 +212,8 @@ _CONFIGS = {
     # not a BASELINE config: C2's Gaussians, 40 % of them gathered in 12 clusters (what a trained scene looks like more than
     # the homogeneous C2 does): long tile lists, pixels with hundreds of blends, blend-log overflow
     "C2L": dict(P=1_000_000, W=1920, H=1080, sigma_min=0.7, sigma_max=7.0, seed=2, clusters=(12, 0.4, 0.03)),
+    # ... and a heavier one (round 6): 60 % in 6 tight clusters -- tile lists beyond the LDS sort's 4096 entries, blend-log overflow on the clusters' tiles
+    "C2H": dict(P=1_000_000, W=1920, H=1080, sigma_min=0.7, sigma_max=7.0, seed=2, clusters=(6, 0.6, 0.012)),
     "L1": dict(P=20_000, W=1920, H=1080, sigma_min=10.0, sigma_max=200.0, seed=6, opacity_range=(0.02, 0.3)),
 }
 
