@@ -39,6 +39,7 @@ struct TileSortArgs {
     int id_passes;            // long segments: counting passes on the id bytes before the depth passes (0: already in id order)
     int gx;                   // tiles per row
     int tile0;                // first tile of the frame's tile-row window (the grid covers the window's tiles)
+    const uint32_t* tile_order; // nullptr, or workgroup j takes tile tile0 + tile_order[j] (longest list first: tile_order_kernel)
     int cull_mask;            // leave every entry's 16-bit sub-tile mask in entF.w (see write_entry): 1 = hierarchical mode's 4x4 culling, 2 = the k-buffer kernel's sub-tile pre-test
     float4* entA; float4* entB; float4* entC; float4* entD; float4* entF;
 };
@@ -119,13 +120,13 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
     constexpr size_t RAW_BYTES = RADIX_BYTES > sizeof(uint64_t) * CAP ? RADIX_BYTES : sizeof(uint64_t) * CAP;
     __shared__ __attribute__((aligned(16))) char s_raw[RAW_BYTES]; // the bitonic network's keys, or the radix sort's exchange area
     uint64_t* const s_key = reinterpret_cast<uint64_t*>(s_raw); // (depth bits << 32) | Gaussian id
-    __shared__ int s_cnt[3 * 256];  // long segments only: digits of a chunk, histogram, bases
+    __shared__ int s_cnt[2 * 256];  // long segments only: histogram / running bases, the waves' counts of a chunk
     const int tid = (int)threadIdx.x;
     // XCD-aware tile order (same map as the render kernels): workgroup ids are dealt round-robin to the 8 XCDs, so each XCD gets
     // a contiguous run of tiles and the 64-byte lines of the Gaussians that neighbouring tiles share hit in that XCD's L2
     const int n_wg = (int)gridDim.x, wg = (int)blockIdx.x;
     const int xq = n_wg >> 3, xr = n_wg & 7, xcd = wg & 7;
-    const int tile = a.tile0 + (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
+    const int tile = a.tile0 + (a.tile_order ? (int)a.tile_order[wg] : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3));
     const uint2 range = a.ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n <= MIN_N || (CAP == TS_SMALL && n > TS_SMALL)) return; // empty, or the other instantiation's tile
@@ -176,51 +177,84 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
     }
 
     // ---- long segment: stable counting passes (LSD: id bytes if needed, then the four depth bytes), keys/list <-> scratch ----
+    // Round 6: ranks by wave ballots.  A chunk of 256 elements is one per thread; the lanes of a wave that hold the SAME digit find each other
+    // with eight ballots (one per digit bit), a lane's rank among them is a popcount, the waves' counts per digit meet in LDS and the thread
+    // that owns a digit advances its base -- three barriers per chunk and no loop over the chunk.  (Rounds 1-5 counted "how many of the
+    // threads below me hold my digit" with a 256-iteration loop per element and pass: 5.1 ms of sort stage on C2H, whose clusters' tiles
+    // hold up to 20 000 entries; a pass skips itself when every key has the same digit.)
     if constexpr (CAP == TS_SMALL) return; // (not reached: those tiles belong to the large instantiation)
-    int* const s_dig = s_cnt;         // [256] digit of the chunk's elements
-    int* const s_hist = s_cnt + 256;  // [256]
-    int* const s_base = s_cnt + 512;  // [256]
+    int* const s_hist = s_cnt;         // [256] histogram of the pass, then the running base of every digit
+    int* const s_wcnt = s_cnt + 256;   // [256] per digit: the four waves' counts of it in the current chunk, one 8-bit field per wave
     uint64_t* src_k = keys; uint32_t* src_v = list;
     uint64_t* dst_k = a.keys_scratch + range.x; uint32_t* dst_v = a.list_scratch + range.x;
     const int n_pass = a.id_passes + 4;
+    const int wv = tid >> 6, ln = tid & 63;
+    const unsigned long long lt_mask = (1ull << ln) - 1ull;
+    int done_passes = 0;
     for (int pass = 0; pass < n_pass; pass++) {
         const bool on_id = pass < a.id_passes;
         const int shift = 8 * (on_id ? pass : pass - a.id_passes);
         auto digit = [&](uint64_t k, uint32_t v) __attribute__((always_inline)) { return (int)(((on_id ? (uint64_t)v : k) >> shift) & 0xFF); };
         s_hist[tid] = 0;
+        s_wcnt[tid] = 0;
         __syncthreads();
         for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[digit(src_k[i], src_v[i])], 1);
         __syncthreads();
-        if (tid == 0) {
-            int acc = 0;
-            for (int d = 0; d < 256; d++) { s_base[d] = acc; acc += s_hist[d]; }
+        const bool same = s_hist[digit(src_k[0], src_v[0])] == n; // (workgroup-uniform: every thread reads the same word) nothing to order in this pass
+        __syncthreads();
+        if (same) continue;
+        if (tid < 64) { // exclusive scan of the 256 counters by one wave, four per lane
+            int c[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { c[k] = s_hist[4 * tid + k]; sum += c[k]; }
+            int inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(inc, o); if (tid >= o) inc += v; }
+            int run = inc - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { s_hist[4 * tid + k] = run; run += c[k]; }
         }
         __syncthreads();
         for (int c0 = 0; c0 < n; c0 += 256) { // chunks in order: the pass is stable
             const int i = c0 + tid;
             const bool valid = i < n;
-            uint64_t k = 0; uint32_t v = 0; int d = -1;
+            uint64_t k = 0; uint32_t v = 0; int d = 0;
             if (valid) { k = src_k[i]; v = src_v[i]; d = digit(k, v); }
-            s_dig[tid] = d;
+            unsigned long long peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++) {
+                const bool one = ((d >> bit) & 1) != 0;
+                const unsigned long long bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            const int rank = __popcll(peers & lt_mask), cnt = __popcll(peers);
+            // my wave's count of digit d, in its 8-bit field of the digit's word (a chunk holds at most 64 of a digit per wave: counts 0..64 fit)
+            if (valid && rank == 0) atomicAdd(&s_wcnt[d], cnt << (8 * wv));
             __syncthreads();
             if (valid) {
-                int r = 0;
-                for (int u = 0; u < tid; u++) r += (int)(s_dig[u] == d);
-                dst_k[s_base[d] + r] = k;
-                dst_v[s_base[d] + r] = v;
+                const unsigned int wc = (unsigned int)s_wcnt[d];
+                const int below = (int)((wv > 0 ? (wc & 0xFFu) : 0u) + (wv > 1 ? ((wc >> 8) & 0xFFu) : 0u) + (wv > 2 ? ((wc >> 16) & 0xFFu) : 0u));
+                const int at = s_hist[d] + below + rank;
+                dst_k[at] = k;
+                dst_v[at] = v;
             }
             __syncthreads();
-            int cnt = 0; // thread t owns digit t: advance its base by this chunk's count
-            for (int u = 0; u < 256; u++) cnt += (int)(s_dig[u] == tid);
-            s_base[tid] += cnt;
+            { // thread t owns digit t: advance its base by the chunk's count of it, clear the waves' counts
+                const unsigned int wc = (unsigned int)s_wcnt[tid];
+                if (wc != 0u) {
+                    s_hist[tid] += (int)((wc & 0xFFu) + ((wc >> 8) & 0xFFu) + ((wc >> 16) & 0xFFu) + (wc >> 24));
+                    s_wcnt[tid] = 0;
+                }
+            }
             __syncthreads();
         }
         uint64_t* tk = src_k; src_k = dst_k; dst_k = tk;
         uint32_t* tv = src_v; src_v = dst_v; dst_v = tv;
+        done_passes++;
         __threadfence_block();
         __syncthreads();
     }
-    if (n_pass & 1) { // an odd number of passes leaves the result in the scratch arrays
+    if (done_passes & 1) { // an odd number of passes leaves the result in the scratch arrays
         for (int i = tid; i < n; i += 256) { keys[i] = src_k[i]; list[i] = src_v[i]; }
         __threadfence_block();
         __syncthreads();
@@ -245,6 +279,8 @@ hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g,
     a.gx = f.gx;
     a.tile0 = f.gx * f.ty0;
     a.cull_mask = subtile_mask_kind(f.s);
+    static const bool ordered = [] { const char* e = std::getenv("STP_GATHER_ORDER"); return e && e[0] == '1'; }(); // experiment (round 6)
+    a.tile_order = (ordered && tile_order_enabled() && !unordered) ? img.tile_cursor + f.gx * f.ty0 : nullptr;
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     const int n_tiles = f.gx * (f.ty1 - f.ty0);
     if (n_tiles <= 0) return hipSuccess;
