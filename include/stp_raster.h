@@ -109,6 +109,14 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user,
                 const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered,
                 float* out_color, int* radii, int debug, void* stream);
 
+/* Extension (not in the reference), for tile-row sharding: the NEXT stp_forward of the calling thread launches its render kernel twice -- tile
+   rows [tile_y0, tile_row) first, then [tile_row, tile_y1) -- and records `event` (a hipEvent_t of the caller) on the stream between the two
+   launches: when the event has fired, the pixel rows above 16 * tile_row are final, and a rank can put them on the wire while the rest of its
+   strip is still being blended.  Same kernels and per-tile work as one launch: pixels, buffers and the backward are unchanged.  A tile_row
+   outside (tile_y0, tile_y1), or a call that returns early, records the event behind everything the call enqueued.  event == NULL clears a
+   pending request.  The request is consumed by the next stp_forward whatever its outcome. */
+void stp_set_forward_split(int tile_row, void* event);
+
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:222-257, rasterizer_impl.cu:417-526).
    geom/binning/image buffers are the ones the forward allocated; R is the forward's return value.
    grad_records must be zero-filled by the caller.  The dL_d* outputs need not be (the reference zero-fills them,

@@ -63,6 +63,7 @@ struct Api {
     decltype(&stp_last_error) last_error = nullptr;
     decltype(&stp_abi_version) abi_version = nullptr;
     decltype(&stp_forget_buffer) forget_buffer = nullptr;
+    decltype(&stp_set_forward_split) set_forward_split = nullptr;
 } g_api;
 
 int load_library(const std::string& path)
@@ -77,7 +78,8 @@ int load_library(const std::string& path)
     a.last_error = reinterpret_cast<decltype(a.last_error)>(dlsym(h, "stp_last_error"));
     a.abi_version = reinterpret_cast<decltype(a.abi_version)>(dlsym(h, "stp_abi_version"));
     a.forget_buffer = reinterpret_cast<decltype(a.forget_buffer)>(dlsym(h, "stp_forget_buffer"));
-    if (!a.forget_buffer || !a.forward || !a.backward_phases || !a.mark_visible || !a.last_error || !a.abi_version)
+    a.set_forward_split = reinterpret_cast<decltype(a.set_forward_split)>(dlsym(h, "stp_set_forward_split"));
+    if (!a.set_forward_split || !a.forget_buffer || !a.forward || !a.backward_phases || !a.mark_visible || !a.last_error || !a.abi_version)
         throw std::runtime_error(path + " does not export the C ABI of include/stp_raster.h");
     if (a.abi_version() != STP_ABI_VERSION) throw std::runtime_error(path + ": ABI version mismatch");
     g_api = a; // (a previously loaded library stays mapped: buffers of its forwards may still be in flight)
@@ -469,6 +471,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("check_scratch", &check_scratch);
     m.def("release_scratch", &release_scratch);
     m.def("forget_unless_same_storage", &forget_unless_same_storage);
+    m.def("set_forward_split", [](int tile_row, uintptr_t event) { need_library(); g_api.set_forward_split(tile_row, reinterpret_cast<void*>(event)); },
+          "the next rasterize_gaussians of this thread renders tile rows below / from tile_row in two launches with `event` (a hipEvent_t handle) recorded between them");
     m.def("clear_scratch_pool", &clear_scratch_pool);
     m.def("set_scratch_pool_limit", &set_scratch_pool_limit);
     m.def("pooled_sizes", &pooled_sizes);

@@ -676,6 +676,16 @@ size_t stp_timing_text(char* buf, size_t size)
     return text.size();
 }
 
+// stp_set_forward_split: the request of the calling thread for its NEXT stp_forward (consumed there, whatever the call's outcome)
+struct ForwardSplit { int row = 0; hipEvent_t event = nullptr; bool armed = false; };
+thread_local ForwardSplit t_forward_split;
+void stp_set_forward_split(int tile_row, void* event)
+{
+    t_forward_split.row = tile_row;
+    t_forward_split.event = (hipEvent_t)event;
+    t_forward_split.armed = event != nullptr;
+}
+
 int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn binning_alloc, void* binning_user,
                 stp_alloc_fn image_alloc, void* image_user, int P, int D, int M, const float* background, int width, int height,
                 const StpSettings* settings, const float* means3D, const float* shs, const float* colors_precomp,
@@ -685,6 +695,12 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
                 void* stream)
 {
     hipStream_t st = (hipStream_t)stream;
+    const ForwardSplit split = t_forward_split; // (one forward per request)
+    t_forward_split = ForwardSplit{};
+    struct SplitGuard { // whatever happens to the call: the caller's event is recorded on its stream behind everything this call enqueued
+        const ForwardSplit& s; hipStream_t st; bool done = false;
+        ~SplitGuard() { if (s.armed && !done) (void)hipEventRecord(s.event, st); }
+    } split_guard{split, st};
     if (!settings || !geometry_alloc || !binning_alloc || !image_alloc) return fail(STP_ERR_INVALID_ARGUMENT, "null settings or allocator");
     if (P < 0 || width <= 0 || height <= 0) return fail(STP_ERR_INVALID_ARGUMENT, "bad sizes");
     if (P == 0) return 0; // reference rasterize_points.cu:93 -- nothing launched, caller's zero image stands
@@ -868,7 +884,17 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         STP_DEBUG_SYNC("entry gather");
         g_timer.mark(3, st);
         std::string err;
-        hipError_t e = launch_render_forward(f, g, b, img, out_color, st, &err);
+        hipError_t e;
+        if (split.armed && split.row > f.ty0 && split.row < f.ty1 && f.s.debug_visualization == 0) {
+            // two launches, tile rows [ty0, row) and [row, ty1), the caller's event between them: a tile-row shard sends the first half of its
+            // strip while the second half renders (include/stp_raster.h: stp_set_forward_split).  Same kernels, same per-tile work, same pixels.
+            FrameParams f1 = f, f2 = f;
+            f1.ty1 = split.row; f2.ty0 = split.row;
+            f1.split_launch = f2.split_launch = 1;
+            e = launch_render_forward(f1, g, b, img, out_color, st, &err);
+            if (e == hipSuccess) { e = hipEventRecord(split.event, st); split_guard.done = e == hipSuccess; }
+            if (e == hipSuccess) e = launch_render_forward(f2, g, b, img, out_color, st, &err);
+        } else e = launch_render_forward(f, g, b, img, out_color, st, &err);
         if (e != hipSuccess) {
             if (!err.empty()) return fail(STP_ERR_QUEUE_SIZE, err);
             return fail_hip(e, "render launch");

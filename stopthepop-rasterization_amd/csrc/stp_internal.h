@@ -159,6 +159,7 @@ struct FrameParams {
     int log_depth;       // depth of this frame's blend log (forward: chosen by log_depth_for; backward: the forward's)
     uint32_t* log_need;  // forward: device word the recording kernels report their largest blend count per pixel to (or nullptr)
     uint32_t log_tag;    // ... tagged with 16 bits of the frame's kind
+    int split_launch = 0; // this FrameParams describes ONE of the two render launches of a split forward (stp_set_forward_split): no tile order of the whole window
     int wild_cov; // forward, after the status read-back: some visible Gaussian has a Sigma^-1 entry >= 1e36 or not finite (depth keys then take the reciprocal with its domain check)
 };
 

@@ -285,6 +285,13 @@ def check_scratch(buf: torch.Tensor, generation: int) -> None:
     _native().check_scratch(buf, int(generation))
 
 
+def set_forward_split(tile_row: int, event) -> None:
+    """The next rasterize_gaussians of this thread launches its render kernel for the tile rows below `tile_row` first and records `event`
+    (a torch.cuda.Event that has been recorded once, so that its handle exists) on the current stream before it launches the rest
+    (include/stp_raster.h: stp_set_forward_split; tile_shard.py sends the first half of a strip behind it)."""
+    _native().set_forward_split(int(tile_row), int(event.cuda_event))
+
+
 def release_scratch(buf: torch.Tensor) -> None:
     """Hand a pooled buffer back after the backward that consumed it (reuse is ordered behind the releasing stream)."""
     _native().release_scratch(buf)

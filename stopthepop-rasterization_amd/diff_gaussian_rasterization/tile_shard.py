@@ -92,13 +92,37 @@ def _host_staged(dist) -> bool:
         return False
 
 
-def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, dst: int = 0, to_all: bool = False):
+def split_row(part: Tuple[int, int]) -> int:
+    """Tile row at which a rank's block is rendered in two launches (0: one launch).  The same function on every rank: the root needs the
+    peers' split rows to post its receives."""
+    y0, y1 = part
+    return (y0 + y1) // 2 if y1 - y0 >= 2 else 0
+
+
+_comm_streams = {}
+
+
+def _comm_stream(device):
+    """One side stream per device for the strip exchange: the collective library orders an operation behind the stream that is CURRENT when it
+    is posted, so operations posted under this stream wait for what this stream waited for -- not for the whole render."""
+    key = torch.device(device).index
+    if key not in _comm_streams:
+        _comm_streams[key] = torch.cuda.Stream(device=device)
+    return _comm_streams[key]
+
+
+def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, dst: int = 0, to_all: bool = False, halves=None):
     """Exchange step of the forward.  `local_image` is this rank's (3,H,W) output with its own pixel rows rendered.
     Root gather (default): in CHW layout a rank's strip is THREE contiguous segments (one per channel); every peer
     sends its three segments and the root receives them straight into the rows of ITS OWN output tensor -- one grouped
     batch of point-to-point operations (ncclGroupStart/End under batch_isend_irecv), every peer -> root transfer on its
     own xGMI link, no padding, no staging copy, no assembly pass.  Returns the assembled frame (the
     root's local_image itself, completed in place) on `dst`, None elsewhere.
+    halves = (start_event, first_half_event) (round 6): every rank rendered its block in two launches split at split_row(part) and
+    first_half_event fires between them (_C.set_forward_split).  A peer then sends the upper half of its strip as soon as that event has
+    fired -- while the lower half is still being blended -- and the root posts ALL its receives at once on the side stream (they land in rows
+    its own render never touches; start_event, recorded before the forward, keeps them behind whatever used the tensor's memory before).
+    Two batches per peer instead of one; the bytes, the landing addresses and the assembled frame are the same.
     to_all: every rank needs the frame -> all-gather of equal-size padded strips + one assembly copy."""
     H = local_image.shape[1]
     if to_all:
@@ -111,32 +135,63 @@ def gather_image(local_image: torch.Tensor, parts, rank: int, world: int, dist, 
         out = assemble(bufs, parts, H)
         return out.to(local_image.device) if staged else out
     staged = _host_staged(dist) and local_image.is_cuda
-    ops, landing = [], []
+
+    def pieces(part):
+        """Pixel-row ranges of a rank's strip in sending order: [upper half, lower half] of a split block, else the whole strip."""
+        py0, py1 = strip_pixels(part, H)
+        ym = split_row(part) if halves is not None else 0
+        pm = min(ym * 16, H)
+        if ym and py0 < pm < py1:
+            return [(py0, pm), (pm, py1)]
+        return [(py0, py1)] if py1 > py0 else []
+
+    batches, landing = [[], []], []   # batch 0: upper halves (or whole strips), batch 1: lower halves
     if rank == dst:
         for r in range(world):
-            py0, py1 = strip_pixels(parts[r], H)
-            if r == dst or py1 <= py0:
+            if r == dst:
                 continue
-            for c in range(local_image.shape[0]):
-                seg = local_image[c, py0:py1, :]                      # contiguous: rows of one channel
-                buf = torch.empty(seg.shape, dtype=seg.dtype) if staged else seg
-                landing.append((seg, buf))
-                ops.append(dist.P2POp(dist.irecv, buf, r))
+            for n, (a, b) in enumerate(pieces(parts[r])):
+                for c in range(local_image.shape[0]):
+                    seg = local_image[c, a:b, :]                      # contiguous: rows of one channel
+                    buf = torch.empty(seg.shape, dtype=seg.dtype) if staged else seg
+                    landing.append((seg, buf))
+                    batches[n].append(dist.P2POp(dist.irecv, buf, r))
     else:
-        py0, py1 = strip_pixels(parts[rank], H)
-        if py1 > py0:
+        for n, (a, b) in enumerate(pieces(parts[rank])):
             for c in range(local_image.shape[0]):
-                seg = local_image[c, py0:py1, :]
-                ops.append(dist.P2POp(dist.isend, seg.cpu() if staged else seg, dst))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+                seg = local_image[c, a:b, :]
+                batches[n].append(dist.P2POp(dist.isend, seg.cpu() if staged else seg, dst))
+    reqs = []
+    overlapped = halves is not None and not staged and local_image.is_cuda
+    if overlapped:
+        start_event, first_half_event = halves
+        comm = _comm_stream(local_image.device)
+        comm.wait_event(start_event)
+        if rank == dst:
+            with torch.cuda.stream(comm):           # every receive now: none of them waits for the root's own render
+                for ops in batches:
+                    if ops:
+                        reqs += dist.batch_isend_irecv(ops)
+        else:
+            comm.wait_event(first_half_event)
+            with torch.cuda.stream(comm):           # the upper half behind the first launch ...
+                if batches[0]:
+                    reqs += dist.batch_isend_irecv(batches[0])
+            if batches[1]:                          # ... the lower half behind the second (the current stream)
+                reqs += dist.batch_isend_irecv(batches[1])
+    else:
+        for ops in batches:
+            if ops:
+                reqs += dist.batch_isend_irecv(ops)
+    for req in reqs:
+        req.wait()                                   # (RCCL: the current stream waits for the operation; gloo: the host does)
     if staged:
         for seg, buf in landing:
             seg.copy_(buf)
     return local_image if rank == dst else None
 
 
+SPLIT_FORWARD = True   # (module switch: False restores the single launch + one batch of rounds 1-5)
 RECORD_USED = 9  # floats of a gradient record that carry data (include/stp_raster.h, stp_backward)
 RECORD_CHUNKS = 2  # pieces the record all-reduce is pipelined in against the per-Gaussian half of the backward (_ShardedRasterize.backward)
 
@@ -202,7 +257,20 @@ class _ShardedRasterize(torch.autograd.Function):
         args = (rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
                 rs.viewmatrix, rs.projmatrix, rs.inv_viewprojmatrix, rs.tanfovx, rs.tanfovy, rs.image_height,
                 rs.image_width, sh, rs.sh_degree, rs.campos, rs.prefiltered, sdict, rs.render_depth, rs.debug)
+        # the render in two launches with an event between them, so that the first half of the strip can leave while the second is blended
+        # (gather_image); the assembled frame is the same with or without
+        halves = None
+        ym = split_row((y0, y1))
+        if world > 1 and not to_all and means3D.is_cuda and means3D.size(0) != 0 and SPLIT_FORWARD:
+            start_ev, half_ev = torch.cuda.Event(), torch.cuda.Event()
+            start_ev.record()     # (also what keeps the root's early receives behind earlier users of the output tensor's memory)
+            half_ev.record()      # (torch creates the hipEvent at the first record: the library needs its handle)
+            if ym:
+                _C.set_forward_split(ym, half_ev)
+            halves = (start_ev, half_ev)
         num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        if halves is not None and not ym:
+            halves[1].record()    # (a block of one tile row is one launch: its "first half" is the whole strip)
         if ctx.log_lease is not None:   # the library chose the log's depth for this frame: account what the buffer really holds
             ctx.log_lease.resize(_C.blend_log_bytes(rs.image_width, rs.image_height, rows, depth=_C.blend_log_depth(imgBuffer)))
         ctx.rs, ctx.sdict, ctx.shard, ctx.num_rendered = rs, sdict, shard, num_rendered
@@ -220,7 +288,7 @@ class _ShardedRasterize(torch.autograd.Function):
             pending = torch.zeros(n_rows, dtype=torch.float32, device=r.device)
             pending[rows[0]:rows[1]] = (r[:, 1] - r[:, 0]).reshape(rows[1] - rows[0], gx).sum(dim=1).to(torch.float32)
             shard_state["pending"] = pending
-        full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all)
+        full = gather_image(color, parts, rank, world, dist, dst=0, to_all=to_all, halves=halves)
         ctx.mark_non_differentiable(radii)
         # every rank returns a (3,H,W) tensor: the assembled frame where it is available, else the local strip image
         return (full if full is not None else color), radii

@@ -21,6 +21,9 @@ parts = tile_shard.row_partition(tile_shard.tile_rows(sc.H), world)
 local = orc.forward_scene(sc, sd, tile_rows=parts[rank])
 img = tile_shard.gather_image(torch.from_numpy(local.color), parts, rank, world, dist, dst=0)
 img_all = tile_shard.gather_image(torch.from_numpy(local.color), parts, rank, world, dist, to_all=True)
+# the strips in two halves (what the GPU path does around its split render launch; on host tensors: two batches, nothing to overlap)
+img_halves = tile_shard.gather_image(torch.from_numpy(local.color.copy()), parts, rank, world, dist, dst=0, halves=(None, None))
+assert all(0 < tile_shard.split_row(p) - p[0] < p[1] - p[0] for p in parts)
 g = local.backward(sc.dL_dout)  # with a window the oracle's render half only sees this rank's rows
 buf = tile_shard.pack_partials(*(torch.from_numpy(g[k]) for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors")))
 dist.all_reduce(buf)
@@ -34,6 +37,7 @@ assert rel(m2d.numpy(), gfull["dL_dmeans2D"]) < 1e-5 and rel(opac.numpy(), gfull
 assert rel(col.numpy(), gfull["dL_dcolors"]) < 1e-5 and rel(conic.numpy(), gfull["dL_dconic"]) < 1e-5
 if rank == 0:
     assert img is not None and np.array_equal(img.numpy(), full.color)
+    assert img_halves is not None and np.array_equal(img_halves.numpy(), full.color)
     print("GLOO_SHARD_OK")
 else:
     assert img is None

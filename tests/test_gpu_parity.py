@@ -961,6 +961,31 @@ def test_scratch_buffers_describe_themselves(sd):
         _C.set_run_ahead(before)
 
 
+def test_forward_split_renders_the_same_frame_and_fires_its_event_between_the_launches():
+    """stp_set_forward_split (tile-row sharding, round 6): the render kernel in two launches with the caller's event between them -- same pixels,
+    same scratch state, same gradients; the request is consumed by ONE forward."""
+    import torch
+    from diff_gaussian_rasterization import _C
+    sc = scenes.make_scene(**DENSE)
+    for sd in (settings_dict(**FULL_STP), settings_dict(2, per_pixel=8), settings_dict(0)):
+        sd = {**sd, "_record_blend_log": sd["sort_settings"]["sort_mode"] in (2, 3), "_backward_mode": "replay"}
+        ten, ref = _direct_forward(sc, sd)
+        gref = _direct_backward(sc, sd, ten, ref, ref[3], ref[4], ref[5])
+        ev = torch.cuda.Event(); ev.record()
+        _C.set_forward_split(((sc.H + 15) // 16) // 2, ev)
+        ten2, out = _direct_forward(sc, sd)
+        ev.synchronize()
+        assert out[0] == ref[0] and torch.equal(out[1], ref[1]) and torch.equal(out[2], ref[2])
+        got = _direct_backward(sc, sd, ten2, out, out[3], out[4], out[5])
+        for a, b in zip(got, gref):
+            if a is not None and b is not None and b.numel():
+                assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+        _, again = _direct_forward(sc, sd)            # no request pending any more: one launch, same frame
+        assert torch.equal(again[1], ref[1])
+        for o in (ref, out, again):
+            _C.release_scratch(o[5]); _C.release_scratch(o[4])
+
+
 def test_stage_timer_keeps_per_call_times():
     """stp_timing_history: the six stage times of every call since timing_enable(True), in order -- what lets bench.py say WHICH step of a timed
     region was slow and in which stage."""
