@@ -186,6 +186,8 @@ hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int 
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 // Longest-list-first order of the window's tiles for the render kernels' workgroups (into ImageState::tile_cursor, free outside STP_SORT=counters)
 bool tile_order_enabled();
+bool gather_order_enabled();
+int gather_order_mode();
 hipError_t launch_tile_order(const FrameParams& f, const ImageState& img, hipStream_t st);
 hipError_t launch_sh_color(const FrameParams& f, const GeometryState& g, const int* radii, hipStream_t st); // SH -> RGB of the visible Gaussians (after preprocess)
 hipError_t launch_mailbox(const uint32_t* last_offset, const uint32_t* status, uint32_t* mailbox_dev, uint32_t ticket, uint32_t* log_need, hipStream_t st);

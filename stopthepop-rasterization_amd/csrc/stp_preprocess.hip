@@ -612,26 +612,44 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int L, const uint64_t*
 // length, longest first (counting sort on 256 length classes: 16 entries apiece up to 2048, 128 apiece beyond); the render kernels' workgroup j
 // then takes tile order[j].  The entry records are per tile: nothing the render kernels read is shared between neighbouring tiles, so the XCD-aware
 // contiguous order they use otherwise buys them nothing.
-__global__ void __launch_bounds__(1024) tile_order_kernel(int tile0, int T, const uint2* __restrict__ ranges_, uint32_t* __restrict__ order)
+// gather_order (second array, may be nullptr): the same idea for the entry gather, whose workgroups DO share data between neighbouring tiles (the
+// Gaussians' 64-byte lines, in the XCD's L2): every XCD keeps its contiguous run of tiles (workgroup j runs on XCD j mod 8) and takes them longest
+// first INSIDE the run -- workgroup 8 k + x gets the k-th longest tile of XCD x's run.
+__global__ void __launch_bounds__(1024) tile_order_kernel(int tile0, int T, const uint2* __restrict__ ranges_, uint32_t* __restrict__ order, uint32_t* __restrict__ gather_order)
 {
     __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_hx[8 * 256];
     const uint2* __restrict__ ranges = ranges_ + tile0;
     const int tid = (int)threadIdx.x;
     auto klass = [](uint32_t len) { return 255u - (len < 2048u ? (len >> 4) : min(127u, (len - 2048u) >> 7) + 128u); }; // 0 = the longest
+    const int xq = T >> 3, xr = T & 7; // XCD x owns the tiles [x (xq + 1), ...) for x < xr, [xr (xq + 1) + (x - xr) xq, ...) beyond (the kernels' own map)
+    auto xcd_of = [&](int t) { const int cut = xr * (xq + 1); return t < cut ? t / (xq + 1) : xr + (xq ? (t - cut) / xq : 0); };
     if (tid < 256) s_hist[tid] = 0u;
+    for (int i = tid; i < 8 * 256; i += 1024) s_hx[i] = 0u;
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) atomicAdd(&s_hist[klass(ranges[t].y - ranges[t].x)], 1u);
-    __syncthreads();
-    if (tid < 64) { // exclusive scan of the 256 counters by one wave: four per lane
-        uint32_t c[4], sum = 0;
-        for (int k = 0; k < 4; k++) { c[k] = s_hist[4 * tid + k]; sum += c[k]; }
-        uint32_t inc = sum;
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (tid >= o) inc += v; }
-        uint32_t run = inc - sum;
-        for (int k = 0; k < 4; k++) { s_hist[4 * tid + k] = run; run += c[k]; }
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t c = klass(ranges[t].y - ranges[t].x);
+        atomicAdd(&s_hist[c], 1u);
+        if (gather_order) atomicAdd(&s_hx[xcd_of(t) * 256 + c], 1u);
     }
     __syncthreads();
-    for (int t = tid; t < T; t += 1024) order[atomicAdd(&s_hist[klass(ranges[t].y - ranges[t].x)], 1u)] = (uint32_t)t;
+    // exclusive scans of 256 counters by one wave each, four per lane: wave 0 the frame's, waves 1..8 the XCDs'
+    const int wv = tid >> 6, ln = tid & 63;
+    if (wv < (gather_order ? 9 : 1)) {
+        uint32_t* const h = wv == 0 ? s_hist : s_hx + (wv - 1) * 256;
+        uint32_t c[4], sum = 0;
+        for (int k = 0; k < 4; k++) { c[k] = h[4 * ln + k]; sum += c[k]; }
+        uint32_t inc = sum;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if (ln >= o) inc += v; }
+        uint32_t run = inc - sum;
+        for (int k = 0; k < 4; k++) { h[4 * ln + k] = run; run += c[k]; }
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+        const uint32_t c = klass(ranges[t].y - ranges[t].x);
+        order[atomicAdd(&s_hist[c], 1u)] = (uint32_t)t;
+        if (gather_order) { const int x = xcd_of(t); gather_order[8u * atomicAdd(&s_hx[x * 256 + c], 1u) + (uint32_t)x] = (uint32_t)t; }
+    }
 }
 
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float* __restrict__ means3D, const float* __restrict__ view, uint8_t* __restrict__ present)
@@ -792,11 +810,24 @@ bool tile_order_enabled()
     static const bool on = [] { const char* e = std::getenv("STP_TILE_ORDER"); return !(e && e[0] == '0'); }();
     return on;
 }
+// STP_GATHER_ORDER (experiments, round 6; default 0): 0 = the entry gather in the XCD-contiguous spatial order, 1 = longest first inside every XCD's run, 2 = longest first over
+// the frame.  MEASURED (sort stage ms, one box, alternating): 1: C2-full 0.320 -> 0.324, C5 1.110 -> 1.172, C3 0.970 -> 0.955, C2L 0.381 -> 0.372; 2: C2-full 0.311 -> 0.320,
+// C5 1.14 -> 1.21, C3 0.944 -> 0.900, C2L 0.378 -> 0.328 -- what the gather gains at the tail it loses in the L2 (neighbouring tiles share their Gaussians' lines).
+bool gather_order_enabled()
+{
+    return gather_order_mode() != 0;
+}
+int gather_order_mode()
+{
+    static const int m = [] { const char* e = std::getenv("STP_GATHER_ORDER"); return e ? std::atoi(e) : 0; }();
+    return m;
+}
 hipError_t launch_tile_order(const FrameParams& f, const ImageState& img, hipStream_t st)
 {
     const int T = f.gx * (f.ty1 - f.ty0);
     if (T <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, f.gx * f.ty0, T, img.ranges, img.tile_cursor + f.gx * f.ty0);
+    hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, st, f.gx * f.ty0, T, img.ranges, img.tile_cursor + f.gx * f.ty0,
+                       gather_order_enabled() ? img.tile_counts + f.gx * f.ty0 : nullptr);
     return hipGetLastError();
 }
 
