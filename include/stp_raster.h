@@ -183,10 +183,10 @@ size_t stp_geometry_buffer_size(int P, const StpSettings* settings);
 size_t stp_binning_buffer_size(int R);
 size_t stp_image_buffer_size(int width, int height); /* without the optional blend log */
 /* Bytes the blend log adds to the image buffer of a forward with StpSettings.record_blend_log = 1 in the hierarchical / k-buffer modes,
-   for a frame nothing is known about yet: 192 records of 2 bytes per pixel of the 16x16 tile grid + one spare row = 386 B per pixel.
+   for a frame nothing is known about yet: 192 records of 2 bytes per pixel of the 16x16 tile grid + eight spare rows = 400 B per pixel.
    The depth is ADAPTIVE: every recording forward reports the largest number of blends of any of its pixels, and the next forwards of
    the same kind (P, resolution, tile-row window, mode) on the device size their log by it (+12.5 %, multiple of 16, 32..512 records) --
-   258 B per pixel once a frame like BASELINE's C2 (at most 114 blends per pixel) has been seen, 450 B for C5 (195).  A pixel that blends
+   304 B per pixel once a frame like BASELINE's C2 (at most 114 blends per pixel) has been seen, 464 B for C5 (195).  A pixel that blends
    more than its frame's depth flags its tile, whose backward then re-sorts (correct, slow), and the frames after it get the deeper log.
    STP_LOG_DEPTH=n in the environment fixes the depth.  _rows: of a forward restricted to the tile rows [tile_y0, tile_y1). */
 size_t stp_blend_log_bytes(int width, int height);

@@ -183,7 +183,7 @@ def backward_mode() -> str:
 
 
 def blend_log_bytes(width: int, height: int, tile_rows=None, depth=None) -> int:
-    """Bytes of the blend log of one forward at this resolution.  depth = None: of a frame nothing is known about (386 B per pixel of the
+    """Bytes of the blend log of one forward at this resolution.  depth = None: of a frame nothing is known about (400 B per pixel of the
     16x16 tile grid; later frames of the same kind get the depth their predecessors needed: blend_log_depth); depth = n: of a log of n
     records per pixel; depth = 0: of the DEEPEST log a forward may carve (what a memory policy has to budget before the forward has run).
     tile_rows = (y0, y1): of a forward restricted to that tile-row window (a rank of a tile-row shard holds its rows' log only)."""
