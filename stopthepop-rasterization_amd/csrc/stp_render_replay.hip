@@ -4,8 +4,8 @@
 // three-level resort to rediscover the order in which every pixel blended its Gaussians.  MI355X has 288 GB of
 // HBM, so the training forward (render_hier_kernel<..., MODE_FWD_RECORD>, render_kbuffer_kernel<WIN, KB_FWD_RECORD>)
 // simply writes that order down -- 2 bytes (the tile-list position) per blended (pixel, Gaussian) pair,
-// as many records per pixel as the frames before it needed (RenderArgs::log_depth; 192 + one spare row = 386 B per pixel for a frame nothing
-// is known about, 258 B per pixel = 0.54 GB at 1080p once C2's 114 blends per pixel are known) -- and this kernel walks each pixel's log
+// as many records per pixel as the frames before it needed (RenderArgs::log_depth; 192 + eight spare rows = 400 B per pixel for a frame nothing
+// is known about, 304 B per pixel = 0.63 GB at 1080p once C2's 114 blends per pixel are known) -- and this kernel walks each pixel's log
 // front to back.  The gradient maths per pair is the reference's (blend_backward_terms); the result is the same sum
 // in a different order.  Tiles whose log overflowed (a pixel with more than BLEND_LOG_DEPTH blended entries, a list longer than
 // 65535) are flagged by the forward and left to the re-sorting backward kernels, which then run only on those tiles.

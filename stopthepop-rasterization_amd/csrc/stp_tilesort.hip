@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
     constexpr size_t RAW_BYTES = RADIX_BYTES > sizeof(uint64_t) * CAP ? RADIX_BYTES : sizeof(uint64_t) * CAP;
     __shared__ __attribute__((aligned(16))) char s_raw[RAW_BYTES]; // the bitonic network's keys, or the radix sort's exchange area
     uint64_t* const s_key = reinterpret_cast<uint64_t*>(s_raw); // (depth bits << 32) | Gaussian id
-    __shared__ int s_cnt[2 * 256];  // long segments only: histogram / running bases, the waves' counts of a chunk
+    static_assert(CAP != TS_CAP || RAW_BYTES >= sizeof(int) * 13 * 256, "the long-segment path keeps its counters in the sort's LDS area");
     const int tid = (int)threadIdx.x;
     // XCD-aware tile order (same map as the render kernels): workgroup ids are dealt round-robin to the 8 XCDs, so each XCD gets
     // a contiguous run of tiles and the 64-byte lines of the Gaussians that neighbouring tiles share hit in that XCD's L2
@@ -177,28 +177,48 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
     }
 
     // ---- long segment: stable counting passes (LSD: id bytes if needed, then the four depth bytes), keys/list <-> scratch ----
-    // Round 6: ranks by wave ballots.  A chunk of 256 elements is one per thread; the lanes of a wave that hold the SAME digit find each other
-    // with eight ballots (one per digit bit), a lane's rank among them is a popcount, the waves' counts per digit meet in LDS and the thread
-    // that owns a digit advances its base -- three barriers per chunk and no loop over the chunk.  (Rounds 1-5 counted "how many of the
+    // Round 6: ranks by wave ballots.  The lanes of a wave that hold the SAME digit find each other with eight ballots (one per digit bit), a
+    // lane's rank among them is a popcount, the waves' counts per digit meet in LDS and the thread that owns a digit advances its base --
+    // three barriers per chunk of 1024 and no loop over the chunk.  (Rounds 1-5 counted "how many of the
     // threads below me hold my digit" with a 256-iteration loop per element and pass: 5.1 ms of sort stage on C2H, whose clusters' tiles
-    // hold up to 20 000 entries; a pass skips itself when every key has the same digit.)
+    // hold up to 28 000 entries -- now 0.99: what is left is ONE workgroup walking the longest tile; a pass skips itself when every key
+    // has the same digit, and all passes' histograms come from one sweep.)
     if constexpr (CAP == TS_SMALL) return; // (not reached: those tiles belong to the large instantiation)
-    int* const s_hist = s_cnt;         // [256] histogram of the pass, then the running base of every digit
-    int* const s_wcnt = s_cnt + 256;   // [256] per digit: the four waves' counts of it in the current chunk, one 8-bit field per wave
+    // (counters in the LDS area the in-LDS sorts of shorter segments use)
+    int* const s_hist = reinterpret_cast<int*>(s_raw); // [256] the running base of every digit in the current pass
+    int* const s_wcnt = s_hist + 256;                  // [4 rounds][256 digits]: the four waves' counts of the digit in that round of the current chunk, one 8-bit field per wave
+    int* const s_hall = s_hist + 5 * 256;              // [8 passes][256]: every pass's digit histogram, from ONE sweep over the segment (the keys do not change between passes)
     uint64_t* src_k = keys; uint32_t* src_v = list;
     uint64_t* dst_k = a.keys_scratch + range.x; uint32_t* dst_v = a.list_scratch + range.x;
     const int n_pass = a.id_passes + 4;
     const int wv = tid >> 6, ln = tid & 63;
     const unsigned long long lt_mask = (1ull << ln) - 1ull;
     int done_passes = 0;
+    for (int i = tid; i < 8 * 256; i += 256) s_hall[i] = 0;
+    __syncthreads();
+    {   // four elements per thread in flight
+        const int n4 = n & ~1023;
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            uint64_t k[4]; uint32_t v[4]; bool ok[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) { const int i = i0 + 256 * r + tid; ok[r] = i0 < n4 || i < n; k[r] = ok[r] ? src_k[i] : 0ull; v[r] = (ok[r] && a.id_passes) ? src_v[i] : 0u; }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (ok[r]) {
+                    for (int p = 0; p < a.id_passes; p++) atomicAdd(&s_hall[256 * p + (int)((v[r] >> (8 * p)) & 0xFF)], 1);
+#pragma unroll
+                    for (int p = 0; p < 4; p++) atomicAdd(&s_hall[256 * (a.id_passes + p) + (int)((k[r] >> (8 * p)) & 0xFF)], 1);
+                }
+        }
+    }
+    __syncthreads();
     for (int pass = 0; pass < n_pass; pass++) {
         const bool on_id = pass < a.id_passes;
         const int shift = 8 * (on_id ? pass : pass - a.id_passes);
         auto digit = [&](uint64_t k, uint32_t v) __attribute__((always_inline)) { return (int)(((on_id ? (uint64_t)v : k) >> shift) & 0xFF); };
-        s_hist[tid] = 0;
-        s_wcnt[tid] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += 256) atomicAdd(&s_hist[digit(src_k[i], src_v[i])], 1);
+        s_hist[tid] = s_hall[256 * pass + tid];
+#pragma unroll
+        for (int r = 0; r < 4; r++) s_wcnt[256 * r + tid] = 0;
         __syncthreads();
         const bool same = s_hist[digit(src_k[0], src_v[0])] == n; // (workgroup-uniform: every thread reads the same word) nothing to order in this pass
         __syncthreads();
@@ -215,36 +235,56 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
             for (int k = 0; k < 4; k++) { s_hist[4 * tid + k] = run; run += c[k]; }
         }
         __syncthreads();
-        for (int c0 = 0; c0 < n; c0 += 256) { // chunks in order: the pass is stable
-            const int i = c0 + tid;
-            const bool valid = i < n;
-            uint64_t k = 0; uint32_t v = 0; int d = 0;
-            if (valid) { k = src_k[i]; v = src_v[i]; d = digit(k, v); }
-            unsigned long long peers = __ballot(valid);
+        // chunks of 1024 in order (the pass is stable): element c0 + 256 r + tid is thread tid's r-th -- four independent loads in flight per thread,
+        // three barriers per 1024 elements (a 28 000-entry tile of C2H is ONE workgroup's job: its chunks are the stage's critical path)
+        for (int c0 = 0; c0 < n; c0 += 4 * 256) {
+            uint64_t k[4]; uint32_t v[4]; int d[4], rank[4]; bool valid[4];
 #pragma unroll
-            for (int bit = 0; bit < 8; bit++) {
-                const bool one = ((d >> bit) & 1) != 0;
-                const unsigned long long bal = __ballot(one);
-                peers &= one ? bal : ~bal;
+            for (int r = 0; r < 4; r++) {
+                const int i = c0 + 256 * r + tid;
+                valid[r] = i < n;
+                k[r] = 0; v[r] = 0;
+                if (valid[r]) { k[r] = src_k[i]; v[r] = src_v[i]; }
             }
-            const int rank = __popcll(peers & lt_mask), cnt = __popcll(peers);
-            // my wave's count of digit d, in its 8-bit field of the digit's word (a chunk holds at most 64 of a digit per wave: counts 0..64 fit)
-            if (valid && rank == 0) atomicAdd(&s_wcnt[d], cnt << (8 * wv));
-            __syncthreads();
-            if (valid) {
-                const unsigned int wc = (unsigned int)s_wcnt[d];
-                const int below = (int)((wv > 0 ? (wc & 0xFFu) : 0u) + (wv > 1 ? ((wc >> 8) & 0xFFu) : 0u) + (wv > 2 ? ((wc >> 16) & 0xFFu) : 0u));
-                const int at = s_hist[d] + below + rank;
-                dst_k[at] = k;
-                dst_v[at] = v;
-            }
-            __syncthreads();
-            { // thread t owns digit t: advance its base by the chunk's count of it, clear the waves' counts
-                const unsigned int wc = (unsigned int)s_wcnt[tid];
-                if (wc != 0u) {
-                    s_hist[tid] += (int)((wc & 0xFFu) + ((wc >> 8) & 0xFFu) + ((wc >> 16) & 0xFFu) + (wc >> 24));
-                    s_wcnt[tid] = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                d[r] = valid[r] ? digit(k[r], v[r]) : 0;
+                unsigned long long peers = __ballot(valid[r]);
+#pragma unroll
+                for (int bit = 0; bit < 8; bit++) {
+                    const bool one = ((d[r] >> bit) & 1) != 0;
+                    const unsigned long long bal = __ballot(one);
+                    peers &= one ? bal : ~bal;
                 }
+                rank[r] = __popcll(peers & lt_mask);
+                // my wave's count of the digit in round r, in its 8-bit field of the (round, digit) word (at most 64 per wave and round)
+                if (valid[r] && rank[r] == 0) atomicAdd(&s_wcnt[256 * r + d[r]], __popcll(peers) << (8 * wv));
+            }
+            __syncthreads();
+            auto fields = [](unsigned int wc) __attribute__((always_inline)) { return (int)((wc & 0xFFu) + ((wc >> 8) & 0xFFu) + ((wc >> 16) & 0xFFu) + (wc >> 24)); };
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (valid[r]) {
+                    int below = 0;
+#pragma unroll
+                    for (int rr = 0; rr < 4; rr++)
+                        if (rr < r) below += fields((unsigned int)s_wcnt[256 * rr + d[r]]);
+                    const unsigned int wc = (unsigned int)s_wcnt[256 * r + d[r]];
+                    below += (int)((wv > 0 ? (wc & 0xFFu) : 0u) + (wv > 1 ? ((wc >> 8) & 0xFFu) : 0u) + (wv > 2 ? ((wc >> 16) & 0xFFu) : 0u));
+                    const int at = s_hist[d[r]] + below + rank[r];
+                    dst_k[at] = k[r];
+                    dst_v[at] = v[r];
+                }
+            }
+            __syncthreads();
+            { // thread t owns digit t: advance its base by the chunk's count of it, clear the rounds' and waves' counts
+                int tot = 0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned int wc = (unsigned int)s_wcnt[256 * r + tid];
+                    if (wc != 0u) { tot += fields(wc); s_wcnt[256 * r + tid] = 0; }
+                }
+                s_hist[tid] += tot;
             }
             __syncthreads();
         }
@@ -259,8 +299,10 @@ __global__ void __launch_bounds__(256, (CAP == TS_SMALL ? STP_GATHER_WAVES : 4))
         __threadfence_block();
         __syncthreads();
     }
-    if (a.gpack)
+    if (a.gpack) {
+#pragma unroll 4
         for (int i = tid; i < n; i += 256) write_entry(a, (size_t)range.x + i, (int)list[i], tile);
+    }
 }
 
 } // namespace
