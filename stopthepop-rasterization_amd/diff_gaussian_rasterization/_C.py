@@ -289,7 +289,7 @@ def set_forward_split(tile_row: int, event) -> None:
     """The next rasterize_gaussians of this thread launches its render kernel for the tile rows below `tile_row` first and records `event`
     (a torch.cuda.Event that has been recorded once, so that its handle exists) on the current stream before it launches the rest
     (include/stp_raster.h: stp_set_forward_split; tile_shard.py sends the first half of a strip behind it)."""
-    _native().set_forward_split(int(tile_row), int(event.cuda_event))
+    _native().set_forward_split(int(tile_row), 0 if event is None else int(event.cuda_event))   # (None: clear a pending request)
 
 
 def release_scratch(buf: torch.Tensor) -> None:

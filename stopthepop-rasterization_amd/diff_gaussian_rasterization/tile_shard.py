@@ -268,7 +268,11 @@ class _ShardedRasterize(torch.autograd.Function):
             if ym:
                 _C.set_forward_split(ym, half_ev)
             halves = (start_ev, half_ev)
-        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        try:
+            num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians(*args)
+        finally:
+            if halves is not None and ym:
+                _C.set_forward_split(0, None)   # (a forward that raised before the library saw the request must not leave it to the next one)
         if halves is not None and not ym:
             halves[1].record()    # (a block of one tile row is one launch: its "first half" is the whole strip)
         if ctx.log_lease is not None:   # the library chose the log's depth for this frame: account what the buffer really holds

@@ -565,6 +565,33 @@ def test_tile_lists_longer_than_the_lds_sort_capacity():
     assert lens.max() > 4096, lens.ravel()
 
 
+def test_tile_order_changes_no_pixel():
+    """STP_TILE_ORDER (read once per process, so this runs in children): the render kernels' workgroups take the tiles longest list first by default, in
+    the XCD-contiguous spatial order of rounds 1-5 with STP_TILE_ORDER=0 -- a schedule, not a result: image, keys and list are the same bit for bit,
+    gradients to the summation order of the atomics.  The scene is lumpy (clusters), so the two orders really differ."""
+    import os, subprocess, sys, tempfile
+    code = ("import sys, numpy as np; sys.path[:0] = ['tests', 'stopthepop-rasterization_amd', '.']; import conftest;"
+            "from helpers import *; from diff_gaussian_rasterization import scenes;"
+            "sc = scenes.make_scene(P=20000, W=320, H=240, sigma_min=1.0, sigma_max=8.0, seed=77, clusters=(5, 0.6, 0.03));"
+            "out = {};"
+            "[out.update({m: GpuRun(sc, sd, backward=True)}) for m, sd in (('hier', settings_dict(**FULL_STP)), ('kb', settings_dict(2, per_pixel=16)))];"
+            "np.savez(sys.argv[1], **{m + '_' + k: v for m, g in out.items() for k, v in (('color', g.color), ('keys', g.binning_array('keys')), ('list', g.binning_array('point_list')),"
+            " ('g_means', g.grads['dL_dmeans3D']), ('g_sh', g.grads['dL_dsh']), ('g_op', g.grads['dL_dopacity']))})")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        res = {}
+        for mode in ("1", "0"):
+            f = os.path.join(d, f"o{mode}.npz")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=dict(os.environ, STP_TILE_ORDER=mode), cwd=root)
+            res[mode] = dict(np.load(f))
+    for k, a in res["1"].items():
+        b = res["0"][k]
+        if k.endswith(("color", "keys", "list")):
+            assert np.array_equal(a, b), k
+        else:
+            assert _rel(a, b) < 2e-5, (k, _rel(a, b))
+
+
 @pytest.mark.parametrize("scene_kw", [
     "P=3000, W=96, H=80, sigma_min=2.0, sigma_max=12.0, seed=11, camera='orbit'",
     "P=7000, W=24, H=20, sigma_min=6.0, sigma_max=20.0, seed=41, opacity_range=(0.02, 0.2)"], ids=["dense", "lists_over_4096"])
