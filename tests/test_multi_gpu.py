@@ -78,3 +78,108 @@ def test_bench_n2_tile_row_headline_with_frame_shard_side_object():
 def test_bench_n2_frames_headline_keeps_the_tile_row_side_object():
     d = _bench_two_ranks(["--shard", "frames"])
     assert d["scaling"] == "weak" and d["config"]["parallelism"] == "frames2" and d["tile_shard"]["scaling"] == "strong" and d["tile_shard"]["value"] > 0
+
+
+class _InProcessTransport:
+    """Stand-in for torch.distributed with DEVICE-side semantics (what RCCL gives the exchange code and gloo does not): point-to-point operations
+    are ordered behind the stream that is current when they are posted, `wait()` makes the current stream wait, nothing is staged through the host.
+    Two "ranks" are two threads of this process on cuda:0; a send parks (tensor, event) in a queue, the matching receive copies it on its own
+    stream behind that event.  It lets the overlapped branch of tile_shard.gather_image -- side stream, start / half-strip events, two batches --
+    run on a one-GPU box; it says nothing about RCCL itself."""
+
+    isend, irecv = "isend", "irecv"
+
+    def __init__(self, world):
+        import queue
+        self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+        self.posted = []          # (rank, kind, stream id): which stream every operation was posted under
+
+    class P2POp:
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def bind(self, rank):
+        outer = self
+
+        class Bound:
+            isend, irecv, P2POp = outer.isend, outer.irecv, outer.P2POp
+
+            @staticmethod
+            def get_backend():
+                return "nccl"
+
+            @staticmethod
+            def batch_isend_irecv(ops):
+                stream = torch.cuda.current_stream()
+                reqs = []
+                for o in ops:
+                    outer.posted.append((rank, o.op, stream.cuda_stream))
+                    if o.op == "isend":
+                        ev = torch.cuda.Event(); ev.record(stream)
+                        outer.q[(rank, o.peer)].put((o.tensor, ev))
+                        reqs.append(type("Req", (), {"wait": staticmethod(lambda: None)}))
+                    else:
+                        def wait(o=o, stream=stream):
+                            src, ev = outer.q[(o.peer, rank)].get(timeout=60)
+                            with torch.cuda.stream(stream):
+                                stream.wait_event(ev)
+                                o.tensor.copy_(src)
+                            done = torch.cuda.Event(); done.record(stream)
+                            torch.cuda.current_stream().wait_event(done)
+                        reqs.append(type("Req", (), {"wait": staticmethod(wait)}))
+                return reqs
+        return Bound
+
+
+def test_overlapped_strip_exchange_on_one_gpu_with_an_in_process_transport():
+    """The branch of gather_image that only a device-side transport takes: forward in two launches (stp_set_forward_split), the upper half-strip
+    posted under the side stream behind the event between them, the root's receives posted beside its own render.  Two threads = two ranks."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, os.path.join(conftest.ROOT, "tests"))
+    from helpers import FULL_STP, GpuRun, ext_settings, settings_dict
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import scenes, tile_shard
+    dev = torch.device("cuda", 0)
+    world = 2
+    for skw, sd in ((dict(P=6000, W=256, H=208, sigma_min=1.5, sigma_max=12.0, seed=61, camera="orbit"), settings_dict(**FULL_STP)),
+                    (dict(P=4000, W=160, H=144, sigma_min=1.5, sigma_max=10.0, seed=62), settings_dict(2, per_pixel=16))):
+        sc = scenes.make_scene(**skw)
+        full = GpuRun(sc, sd, backward=False)
+        tr = _InProcessTransport(world)
+        out, errors = {}, []
+
+        def run(rank):
+            try:
+                torch.cuda.set_device(dev)
+                t = lambda a: torch.tensor(a, device=dev)
+                rs = dgr.GaussianRasterizationSettings(
+                    image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=t(sc.bg), scale_modifier=sc.scale_modifier,
+                    viewmatrix=t(sc.viewmatrix), projmatrix=t(sc.projmatrix), inv_viewprojmatrix=t(sc.inv_viewprojmatrix), sh_degree=sc.sh_degree,
+                    campos=t(sc.campos), prefiltered=False, settings=ext_settings(sd), render_depth=False, debug=False)
+                r = tile_shard.TileRowShardedRasterizer(rs, tr.bind(rank), rank, world)
+                color, radii = r(t(sc.means3D), torch.zeros(sc.means3D.shape, device=dev), t(sc.opacities), shs=t(sc.shs), scales=t(sc.scales), rotations=t(sc.rotations))
+                torch.cuda.synchronize(dev)
+                out[rank] = (color.cpu().numpy(), radii.cpu().numpy(), r.parts)
+            except Exception as ex:   # (a thread's exception must fail the test, not vanish)
+                import traceback
+                errors.append(traceback.format_exc())
+
+        threads = [threading.Thread(target=run, args=(k,)) for k in range(world)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=120)
+        assert not errors, errors[0]
+        assert np.array_equal(out[0][0], full.color)                       # the root holds the whole frame, bit for bit
+        parts = out[0][2]
+        assert all(tile_shard.split_row(p) for p in parts)                 # both blocks were rendered in two launches
+        y0, y1 = parts[1]
+        assert np.array_equal(out[1][0][:, 16 * y0:min(16 * y1, sc.H)], full.color[:, 16 * y0:min(16 * y1, sc.H)])   # the peer keeps its own strip
+        # the upper halves (and every receive of the root) were posted under a stream that is not the ranks' compute stream
+        compute = torch.cuda.current_stream(dev).cuda_stream
+        side = {s for (_, _, s) in tr.posted if s != compute}
+        assert side, tr.posted
+        assert all(s != compute for (rk, kind, s) in tr.posted if rk == 0 and kind == "irecv")
+        assert sum(1 for (rk, kind, s) in tr.posted if rk == 1 and kind == "isend" and s != compute) == 3    # three channel segments of the upper half
+        assert sum(1 for (rk, kind, s) in tr.posted if rk == 1 and kind == "isend" and s == compute) == 3    # ... and of the lower half
