@@ -114,6 +114,45 @@ template <bool BLOCKED> __device__ __forceinline__ uint32_t log_record_offset(ui
     if constexpr ((BLOCKED && STP_LOG_LAYOUT != 1) || STP_LOG_LAYOUT == 2) return (((j2 << 6) & ~(128u * LOG_BLOCK - 1u)) | lane16) | (j2 & (2u * LOG_BLOCK - 2u));
     else return (j2 << 6) | (lane16 >> (LOG_PIECE_SHIFT - 1));
 }
+// The k-buffer forwards' log cursor (blocked layout).  A lane's four consecutive records are ONE 8-byte piece: they are collected in two registers -- a
+// 64-bit shift register, the newest record enters at the top -- and stored as a whole piece when the fourth has arrived: a quarter of the store
+// instructions, every one a complete piece, a 128-byte line complete after sixteen of them.  MEASURED (round 6, one box, alternating, C3): forward
+// 2.02-2.11 -> 1.91-1.94 ms, 1.78 -> 1.24 GB written per launch (2-byte stores from the blending lanes: the line of a piece was dirtied four times).
+#ifndef STP_KB_LOG_PIECES
+#define STP_KB_LOG_PIECES (STP_LOG_BLOCK == 4 && STP_LOG_LAYOUT != 1)
+#endif
+struct BlockedLogCursor {
+    char* wave;          // the wave's slice
+    uint32_t cap2;       // 2 * depth: cursor of the first record that does not fit
+    uint32_t piece;      // lane << LOG_PIECE_SHIFT
+    uint32_t j2 = 0u;    // 2 * records so far (also beyond the depth)
+    uint32_t lo = 0u, hi = 0u;
+    __device__ __forceinline__ void append(bool upd, int pay)
+    {
+#if STP_KB_LOG_PIECES
+        if (upd) {
+            lo = __builtin_amdgcn_alignbit(hi, lo, 16);            // {hi, lo} >> 16
+            hi = __builtin_amdgcn_alignbit((uint32_t)pay, hi, 16); // ... and the record into the top 16 bits
+            if ((j2 & 6u) == 6u && j2 < cap2) *reinterpret_cast<uint2*>(wave + log_record_offset<true>(j2 & ~6u, piece)) = make_uint2(lo, hi);
+        }
+#else
+        if (upd && j2 < cap2) *reinterpret_cast<log_t*>(wave + log_record_offset<true>(j2, piece)) = (log_t)pay;
+#endif
+        j2 += upd ? 2u : 0u;
+    }
+    __device__ __forceinline__ int records() const { return (int)(j2 >> 1); }
+    __device__ __forceinline__ void flush() // the last, incomplete piece: its records sit at the TOP of the shift register
+    {
+#if STP_KB_LOG_PIECES
+        const uint32_t have = (j2 >> 1) & 3u;
+        if (have != 0u && (j2 & ~6u) < cap2) { // (the piece starts below the cap: depths are multiples of eight, a piece never straddles it)
+            const unsigned long long acc = ((((unsigned long long)hi) << 32) | lo) >> (16u * (4u - have));
+            *reinterpret_cast<uint2*>(wave + log_record_offset<true>(j2 & ~6u, piece)) = make_uint2((uint32_t)acc, (uint32_t)(acc >> 32));
+        }
+#endif
+    }
+};
+
 // what a recording forward reports back: the largest number of blends of any of its pixels (one compare per wave, an atomic only while
 // the maximum still rises), collected per device and kind and handed to the host with the next forward's num_rendered
 // (the word carries the reporting kind's tag in its upper half: a forward of another kind that shares the slot does not take the report for its own)

@@ -130,19 +130,11 @@ __global__ void __launch_bounds__(256, kb_waves<WIN>()) render_kbuffer_wave_kern
         return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4));
     };
 
-    // blend log (recording forward): as in stp_render_hier.inc
-    char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr;
-    // (layout [record / 8][lane][record % 8], stp_blend.h; conditional stores: the lanes of this kernel blend in few of its steps, and a store
-    // that re-dirties the line of a lane's NEXT record in every step costs more than the branch saves -- C3 forward 2.45 -> 2.36 ms, round 6)
-    const uint32_t log_cap2 = 2u * (uint32_t)a.log_depth;
-    const uint32_t log_lane16 = (uint32_t)lane << LOG_PIECE_SHIFT;
-    uint32_t log_j2 = 0u;
-    auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
-        if (upd && log_j2 < log_cap2) *reinterpret_cast<log_t*>(log_wave + log_record_offset<true>(log_j2, log_lane16)) = (log_t)pay;
-        log_j2 += upd ? 2u : 0u;
-    };
-    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_j2 >> 1); };
-    auto log_finish = [&]() __attribute__((always_inline)) {};
+    // blend log (recording forward): blocked layout, whole pieces from blending lanes only (stp_blend.h: BlockedLogCursor)
+    BlockedLogCursor logc{RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr, 2u * (uint32_t)a.log_depth, (uint32_t)lane << LOG_PIECE_SHIFT};
+    auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) { logc.append(upd, pay); };
+    auto log_records = [&]() __attribute__((always_inline)) -> int { return logc.records(); };
+    auto log_finish = [&]() __attribute__((always_inline)) { logc.flush(); };
 
     Window<WIN> head;
     head.init_padded();
@@ -410,24 +402,21 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
         return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + ((uint32_t)pos << 4));
     };
 
-    // blend log (recording forward): as in stp_render_hier.inc -- the record goes to the lane's current slot in every step (a later blend overwrites
-    // it; behind the log's depth everything lands in the spare row), only the cursor's advance is conditional
-    char* const log_wave = RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr;
-    const uint32_t log_cap2 = 2u * (uint32_t)a.log_depth;
-    const uint32_t log_lane16 = (uint32_t)lane << LOG_PIECE_SHIFT;
-    uint32_t log_j2 = 0u;
+    // blend log (recording forward): blocked layout, whole pieces from blending lanes only (stp_blend.h: BlockedLogCursor)
+    BlockedLogCursor logc{RECORD ? log_wave_slice(a.blend_log, tile, w, a.log_depth) : nullptr, 2u * (uint32_t)a.log_depth, (uint32_t)lane << LOG_PIECE_SHIFT};
     auto log_append = [&](bool upd, int pay) __attribute__((always_inline)) {
-#if defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 1   // timing experiment (log WRONG): every store of the wave into its first block -- same instructions, eight lines
-        *reinterpret_cast<log_t*>(log_wave + log_lane16) = (log_t)pay;
+#if defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 1   // timing experiment (log WRONG): every store of the wave into its first block -- same instructions, few lines
+        *reinterpret_cast<log_t*>(logc.wave + logc.piece) = (log_t)pay; logc.j2 += upd ? 2u : 0u;
 #elif defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 2 // ... no store at all
-#elif defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 4 // ... the unconditional store of rounds 4-5 (into the slot of the lane's next record, or the spare block)
-        *reinterpret_cast<log_t*>(log_wave + log_record_offset<true>(min(log_j2, log_cap2), log_lane16)) = (log_t)pay;
+        logc.j2 += upd ? 2u : 0u;
+#elif defined(STP_KB_LOG_ABLATE) && STP_KB_LOG_ABLATE == 4 // ... the unconditional 2-byte store of rounds 4-5 (into the slot of the lane's next record, or the spare block)
+        *reinterpret_cast<log_t*>(logc.wave + log_record_offset<true>(min(logc.j2, logc.cap2), logc.piece)) = (log_t)pay; logc.j2 += upd ? 2u : 0u;
 #else
-        if (upd && log_j2 < log_cap2) *reinterpret_cast<log_t*>(log_wave + log_record_offset<true>(log_j2, log_lane16)) = (log_t)pay;
+        logc.append(upd, pay);
 #endif
-        log_j2 += upd ? 2u : 0u;
     };
-    auto log_records = [&]() __attribute__((always_inline)) -> int { return (int)(log_j2 >> 1); };
+    auto log_records = [&]() __attribute__((always_inline)) -> int { return logc.records(); };
+    auto log_flush = [&]() __attribute__((always_inline)) { logc.flush(); };
 
     // the ring: logical entry k of my window lives in slot (rh + k) mod WIN of my column
     const uint32_t col = (uint32_t)threadIdx.x * 8u;
@@ -668,6 +657,7 @@ __global__ void __launch_bounds__(256, kb_ring_waves<WIN>()) render_kbuffer_ring
         cfull = total;
     }
 
+    if constexpr (RECORD) log_flush();
     if (inside) {
         const size_t N = (size_t)a.W * a.H, pid = (size_t)a.W * py + px;
         a.final_T[pid] = fp.T;
