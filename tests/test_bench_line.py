@@ -78,6 +78,19 @@ def test_emit_sheds_optional_objects_instead_of_losing_the_line(tmp_path, monkey
     assert json.load(open(tmp_path / "bench_detail.json"))["other_workloads"].keys() == full["other_workloads"].keys()
 
 
+def test_the_committed_round_6_line_is_what_the_driver_can_parse():
+    """profiles/r06_bench_full.json is the stdout line of the default run on the round's final kernels: one bounded JSON object with the contract's
+    keys, the roofline of both render kernels WITH measured traffic, the CPU baseline, and a traffic figure for every other workload."""
+    text = open(os.path.join(conftest.ROOT, "profiles", "r06_bench_full.json")).read().strip()
+    assert text.count("\n") == 0
+    d = json.loads(text)
+    _check_line(d, text)
+    assert d["roofline"]["traffic"] and d["roofline"]["second"]["traffic"]
+    assert all(w["traffic"] for w in d["other_workloads"].values())
+    assert d["other_workloads"]["C3"]["dominant_kernel"].startswith("render_kbuffer_ring_kernel<16")
+    assert d["leg_seconds"]["total"] < 60.0
+
+
 @pytest.mark.gpu
 def test_bench_prints_one_bounded_line_at_n1():
     env = dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp"))
