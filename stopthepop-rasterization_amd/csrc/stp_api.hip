@@ -882,7 +882,7 @@ int stp_forward(stp_alloc_fn geometry_alloc, void* geometry_user, stp_alloc_fn b
         // behind the order kernel AFTER the caller's stream has been told to wait for its first recording, the colour kernel's -- is joined in front of
         // the render launch.  MEASURED (one box, alternating, sort stage ms): 4K 0.489 -> 0.473; 1080p 0.324 -> 0.329 (C2L, C5 likewise: the two event
         // operations and the company of the gather cost more than seven microseconds hidden) -- so only frames of 16 384 tiles and more take the side stream.
-        const bool order_wanted = !atomic_bin && tile_order_enabled();
+        const bool order_wanted = !atomic_bin && tile_order_used(f);
 #ifdef STP_ORDER_MAIN   // (A/B builds: the order kernel on the caller's stream, in front of the gather)
         const bool order_on_side = false;
 #else

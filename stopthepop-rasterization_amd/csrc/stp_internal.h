@@ -186,6 +186,9 @@ hipError_t launch_frame_init(const GeometryState& g, const ImageState& img, int 
 hipError_t launch_scan(const FrameParams& f, const GeometryState& g, hipStream_t st);
 // Longest-list-first order of the window's tiles for the render kernels' workgroups (into ImageState::tile_cursor, free outside STP_SORT=counters)
 bool tile_order_enabled();
+// ... and does THIS frame use it: a window of up to 1024 tiles is resident on the chip all at once (1024-1280 workgroup slots), an order of its
+// workgroups changes nothing and the 7 us kernel is left out (C1: 256 tiles)
+inline bool tile_order_used(const FrameParams& f) { return tile_order_enabled() && f.gx * (f.ty1 - f.ty0) > 1024; }
 bool gather_order_enabled();
 int gather_order_mode();
 hipError_t launch_tile_order(const FrameParams& f, const ImageState& img, hipStream_t st);

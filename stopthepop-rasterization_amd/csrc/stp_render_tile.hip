@@ -414,7 +414,7 @@ static RenderArgs make_args(const FrameParams& f, const GeometryState& g, const 
     a.final_T = img.final_T; a.n_contrib = img.n_contrib;
     a.blend_log = img.blend_log; a.tile_flags = img.tile_flags; a.flag_mode = 0;
     static const bool counters = [] { const char* e = std::getenv("STP_SORT"); return e && std::strcmp(e, "counters") == 0; }(); // (that path uses tile_cursor itself)
-    a.tile_order = (tile_order_enabled() && !counters && !f.split_launch) ? img.tile_cursor + f.gx * f.ty0 : nullptr;
+    a.tile_order = (tile_order_used(f) && !counters && !f.split_launch) ? img.tile_cursor + f.gx * f.ty0 : nullptr;
     a.log_depth = img.log_depth; a.log_need = f.log_need; a.log_tag = f.log_tag;
     a.debug_depth = f.s.debug_visualization == STP_DEBUG_DEPTH ? 1 : 0; a.means3D = f.means3D;
     return a;

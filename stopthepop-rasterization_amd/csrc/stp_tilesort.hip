@@ -322,7 +322,7 @@ hipError_t launch_tile_sort_gather(const FrameParams& f, const GeometryState& g,
     a.tile0 = f.gx * f.ty0;
     a.cull_mask = subtile_mask_kind(f.s);
     // (STP_GATHER_ORDER: 0 = default: spatial, 1: longest first inside every XCD's contiguous run, 2: longest first over the frame -- tile_order_kernel, measured there)
-    const int gmode = (tile_order_enabled() && !unordered) ? gather_order_mode() : 0;
+    const int gmode = (tile_order_used(f) && !unordered) ? gather_order_mode() : 0;
     a.tile_order = gmode == 1 ? img.tile_counts + f.gx * f.ty0 : gmode == 2 ? img.tile_cursor + f.gx * f.ty0 : nullptr;
     a.entA = b.entA; a.entB = b.entB; a.entC = b.entC; a.entD = b.entD; a.entF = b.entF;
     const int n_tiles = f.gx * (f.ty1 - f.ty0);

@@ -572,7 +572,7 @@ def test_tile_order_changes_no_pixel():
     import os, subprocess, sys, tempfile
     code = ("import sys, numpy as np; sys.path[:0] = ['tests', 'stopthepop-rasterization_amd', '.']; import conftest;"
             "from helpers import *; from diff_gaussian_rasterization import scenes;"
-            "sc = scenes.make_scene(P=20000, W=320, H=240, sigma_min=1.0, sigma_max=8.0, seed=77, clusters=(5, 0.6, 0.03));"
+            "sc = scenes.make_scene(P=30000, W=640, H=480, sigma_min=1.0, sigma_max=8.0, seed=77, clusters=(5, 0.6, 0.03));"   # (1200 tiles: windows of up to 1024 are not ordered)
             "out = {};"
             "[out.update({m: GpuRun(sc, sd, backward=True)}) for m, sd in (('hier', settings_dict(**FULL_STP)), ('kb', settings_dict(2, per_pixel=16)))];"
             "np.savez(sys.argv[1], **{m + '_' + k: v for m, g in out.items() for k, v in (('color', g.color), ('keys', g.binning_array('keys')), ('list', g.binning_array('point_list')),"
